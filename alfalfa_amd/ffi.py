@@ -1,0 +1,301 @@
+"""ctypes binding of libalfa_hot (include/alfa_hot.h, include/alfa_index.h).
+
+This is the thin Python face used by tests/, bench.py and __graft_entry__.py.  It is
+plumbing only: every compute call goes through the C ABI into the HIP kernels.  If the
+shared library has not been built the import of the library fails loudly -- there is
+no Python or CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libalfa_hot.so")
+
+SEED_SMAM, SEED_MEM, SEED_SMEM, SEED_SMEMP = 0, 1, 2, 3
+
+
+class IndexView(C.Structure):
+    _fields_ = [
+        ("S", C.c_void_p), ("N", C.c_int64), ("K", C.c_int64), ("logN", C.c_int64), ("NKm1", C.c_int64),
+        ("SA", C.c_void_p), ("n", C.c_int64),
+        ("LCP", C.c_void_p), ("LCP_M_idx", C.c_void_p), ("LCP_M_val", C.c_void_p), ("nM", C.c_int64),
+        ("CHILD", C.c_void_p), ("ISA", C.c_void_p), ("KMR", C.c_void_p),
+        ("has_child", C.c_int32), ("has_suflink", C.c_int32), ("has_kmer", C.c_int32),
+        ("n_seq", C.c_int32), ("startpos", C.c_void_p),
+    ]
+
+
+class Match(C.Structure):
+    _fields_ = [("ref", C.c_int64), ("query", C.c_int32), ("len", C.c_int32)]
+
+
+MATCH_DTYPE = np.dtype([("ref", "<i8"), ("query", "<i4"), ("len", "<i4")])
+
+
+class SeedQuery(C.Structure):
+    _fields_ = [("P", C.c_char_p), ("plen", C.c_int32), ("min_len", C.c_int32), ("max_count", C.c_int32),
+                ("sparse_q", C.c_int32), ("max_smem_cont", C.c_int32)]
+
+
+class DpTask(C.Structure):
+    _fields_ = [("query", C.c_void_p), ("target", C.c_void_p), ("qlen", C.c_int32), ("tlen", C.c_int32),
+                ("w", C.c_int32), ("h0", C.c_int32)]
+
+
+class DpParams(C.Structure):
+    _fields_ = [("m", C.c_int32), ("mat", C.c_int8 * 64), ("gapo", C.c_int32), ("gape", C.c_int32), ("zdrop", C.c_int32)]
+
+
+class ExtendResult(C.Structure):
+    _fields_ = [("score", C.c_int32), ("qle", C.c_int32), ("tle", C.c_int32), ("gtle", C.c_int32),
+                ("gscore", C.c_int32), ("max_off", C.c_int32)]
+
+
+EXTEND_DTYPE = np.dtype([("score", "<i4"), ("qle", "<i4"), ("tle", "<i4"), ("gtle", "<i4"), ("gscore", "<i4"), ("max_off", "<i4")])
+
+
+class Timing(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
+                ("work_units", C.c_int64), ("launches", C.c_int32)]
+
+
+class AlfaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libalfa_hot.so (built by __graft_entry__.build()).  Fails loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AlfaError("libalfa_hot.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                            "There is no CPU fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.alfa_last_error.restype = C.c_char_p
+        _lib.alfa_host_index_view.restype = C.POINTER(IndexView)
+        _lib.alfa_host_index_descr.restype = C.c_char_p
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AlfaError("libalfa_hot error %d: %s" % (rc, lib().alfa_last_error().decode()))
+
+
+def default_params(match=1, mismatch=-4, open_gap=-6, extend_gap=-1, zdrop=100):
+    """align_opt::fill_m (reference src/options.cpp:33-41) + the sign convention of the ksw callers."""
+    p = DpParams()
+    p.m = 5
+    k = 0
+    for i in range(4):
+        for j in range(4):
+            p.mat[k] = match if i == j else mismatch
+            k += 1
+        p.mat[k] = -1
+        k += 1
+    for j in range(5):
+        p.mat[k] = -1
+        k += 1
+    p.gapo = -open_gap
+    p.gape = -extend_gap
+    p.zdrop = zdrop
+    return p
+
+
+def view_arrays(v):
+    """numpy views (zero-copy) of the arrays behind an IndexView."""
+    def arr(ptr, n, dt):
+        if not ptr or n == 0:
+            return np.zeros(0, dtype=dt)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt)
+    n = v.n
+    return dict(
+        S=arr(v.S, v.N, np.uint8), SA=arr(v.SA, n, np.uint32), LCP=arr(v.LCP, n, np.uint8),
+        LCP_M_idx=arr(v.LCP_M_idx, v.nM, np.int64), LCP_M_val=arr(v.LCP_M_val, v.nM, np.int32),
+        CHILD=arr(v.CHILD, n if v.has_child else 0, np.int32), ISA=arr(v.ISA, n if v.has_suflink else 0, np.int32),
+        KMR=arr(v.KMR, 2 * (1 << 20) if v.has_kmer else 0, np.uint32), startpos=arr(v.startpos, v.n_seq, np.int64),
+    )
+
+
+class HostIndex:
+    """Host-resident enhanced sparse suffix array (alfa_index.h)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.view = lib().alfa_host_index_view(handle).contents
+
+    @classmethod
+    def build_fasta(cls, path, K=12, suflink=False, child=True, kmer=True):
+        h = C.c_void_p()
+        check(lib().alfa_host_index_build_fasta(path.encode(), C.c_int64(K), int(suflink), int(child), int(kmer), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def build_mem(cls, names, seqs, K=12, suflink=False, child=True, kmer=True):
+        n = len(seqs)
+        bs = [s if isinstance(s, bytes) else s.encode() for s in seqs]
+        nm = (C.c_char_p * n)(*[x.encode() for x in names])
+        sq = (C.c_char_p * n)(*bs)
+        ln = (C.c_int64 * n)(*[len(b) for b in bs])
+        h = C.c_void_p()
+        check(lib().alfa_host_index_build_mem(n, nm, sq, ln, C.c_int64(K), int(suflink), int(child), int(kmer), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load(cls, prefix):
+        h = C.c_void_p()
+        check(lib().alfa_host_index_load(prefix.encode(), C.byref(h)))
+        return cls(h)
+
+    def save(self, prefix):
+        check(lib().alfa_host_index_save(self._h, prefix.encode()))
+
+    def arrays(self):
+        return view_arrays(self.view)
+
+    def descr(self, i):
+        return lib().alfa_host_index_descr(self._h, i).decode()
+
+    def chrom_bounds(self, hit):
+        a, b = C.c_int64(), C.c_int64()
+        lib().alfa_host_index_chrom_bounds(self._h, C.c_int64(hit), C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().alfa_host_index_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def make_seed_queries(reads, min_len, max_count, sparse_q, max_smem_cont=0):
+    """reads: list of bytes; scalar or per-read parameter lists."""
+    n = len(reads)
+
+    def per(x):
+        return x if isinstance(x, (list, tuple, np.ndarray)) else [x] * n
+    ml, mc, sq, ms = per(min_len), per(max_count), per(sparse_q), per(max_smem_cont)
+    q = (SeedQuery * n)()
+    for i, r in enumerate(reads):
+        q[i].P = r
+        q[i].plen = len(r)
+        q[i].min_len = int(ml[i])
+        q[i].max_count = int(mc[i])
+        q[i].sparse_q = int(sq[i])
+        q[i].max_smem_cont = int(ms[i])
+    return q
+
+
+def _seed_call(fn, handle_or_view, mem_type, queries, free_fn):
+    nq = len(queries)
+    mptr = C.c_void_p()
+    offs = np.zeros(nq + 1, dtype=np.int64)
+    rc = fn(handle_or_view, int(mem_type), queries, nq, C.byref(mptr), offs.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise AlfaError("seed batch failed rc=%d" % rc)
+    total = int(offs[-1])
+    if total:
+        buf = C.string_at(mptr.value, total * MATCH_DTYPE.itemsize)
+        matches = np.frombuffer(buf, dtype=MATCH_DTYPE).copy()
+    else:
+        matches = np.zeros(0, dtype=MATCH_DTYPE)
+    free_fn(mptr)
+    return matches, offs
+
+
+def make_dp_tasks(pairs, w, h0=0):
+    """pairs: list of (query uint8 ndarray, target uint8 ndarray); returns (ctypes task array, keepalive)."""
+    n = len(pairs)
+
+    def per(x):
+        return x if isinstance(x, (list, tuple, np.ndarray)) else [x] * n
+    ws, h0s = per(w), per(h0)
+    t = (DpTask * n)()
+    keep = []
+    for i, (q, tg) in enumerate(pairs):
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        tg = np.ascontiguousarray(tg, dtype=np.uint8)
+        keep.append((q, tg))
+        t[i].query = q.ctypes.data
+        t[i].target = tg.ctypes.data
+        t[i].qlen = len(q)
+        t[i].tlen = len(tg)
+        t[i].w = int(ws[i])
+        t[i].h0 = int(h0s[i])
+    return t, keep
+
+
+def _global_call(fn, params, tasks, free_fn):
+    n = len(tasks)
+    score = np.zeros(n, dtype=np.int32)
+    ncig = np.zeros(n, dtype=np.int32)
+    coff = np.zeros(n + 1, dtype=np.int64)
+    cptr = C.c_void_p()
+    rc = fn(C.byref(params), tasks, n, score.ctypes.data_as(C.c_void_p), C.byref(cptr), ncig.ctypes.data_as(C.c_void_p),
+            coff.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise AlfaError("ksw_global batch failed rc=%d" % rc)
+    total = int(coff[-1])
+    cig = np.frombuffer(C.string_at(cptr.value, total * 4), dtype=np.uint32).copy() if total else np.zeros(0, np.uint32)
+    free_fn(cptr)
+    return score, cig, ncig, coff
+
+
+class DeviceIndex:
+    """HBM-resident index (alfa_index_upload)."""
+
+    def __init__(self, host_index, device=0):
+        self.host = host_index
+        h = C.c_void_p()
+        check(lib().alfa_index_upload(C.byref(host_index.view), int(device), C.byref(h)))
+        self._h = h
+
+    def seed_batch(self, mem_type, queries):
+        def fn(h, t, q, nq, m, o):
+            rc = lib().alfa_seed_batch(h, t, q, nq, m, o)
+            check(rc)
+            return rc
+        return _seed_call(fn, self._h, mem_type, queries, lib().alfa_free)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().alfa_index_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def ksw_extend_batch(params, tasks):
+    n = len(tasks)
+    out = np.zeros(n, dtype=EXTEND_DTYPE)
+    check(lib().alfa_ksw_extend_batch(C.byref(params), tasks, n, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def ksw_nw_batch(params, tasks):
+    n = len(tasks)
+    out = np.zeros(n, dtype=np.int32)
+    check(lib().alfa_ksw_nw_batch(C.byref(params), tasks, n, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def ksw_global_batch(params, tasks):
+    def fn(*a):
+        rc = lib().alfa_ksw_global_batch(*a)
+        check(rc)
+        return rc
+    return _global_call(fn, params, tasks, lib().alfa_free)
+
+
+def last_timing():
+    t = Timing()
+    check(lib().alfa_last_timing(C.byref(t)))
+    return t

@@ -1,0 +1,168 @@
+/* alfa_hot.h -- C ABI of libalfa_hot: the MI355X-native seed-and-extend hot path.
+ *
+ * Every entry point below is the batch form of one call the reference ALFALFA
+ * mapper makes synchronously, per read, inside its kt_for worker
+ * (reference src/main.cpp:102,126).  The reference has no FFI/plugin layer:
+ * its "interface" for this path is the in-process C/C++ call surface
+ *
+ *   sparseSA::SMAM / MEM / SMEM / SMEMP        src/sparseSA.h:274-283
+ *   ksw_extend / ksw_nw / ksw_global           src/ksw.h:82-83,106
+ *   dynProg::dpBandStatic/Full/Score/dpBasic   src/dp.h:122-135
+ *
+ * and each declaration cites the exact reference signature it replaces.
+ * Conventions: plain pointers and sizes only; return 0 on success or a negative
+ * errno-style code (never exit()); inputs are borrowed for the duration of the
+ * call; outputs documented as "library-allocated" are released with alfa_free().
+ * All entry points are thread-safe; one alfa_index may be shared by any number
+ * of host threads (the reference shares one `const sparseSA&` the same way).
+ *
+ * There is NO CPU fallback in this library: without a usable HIP device every
+ * compute entry point fails with ALFA_ENODEV and alfa_last_error() says why.
+ */
+#ifndef ALFA_HOT_H
+#define ALFA_HOT_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALFA_OK        0
+#define ALFA_EINVAL  (-22)
+#define ALFA_ENOMEM  (-12)
+#define ALFA_ENODEV  (-19)
+#define ALFA_ENOTSUP (-95)
+#define ALFA_EHIP    (-5)
+
+/* seed types == the reference's method names (NOT the shifted CLI names,
+ * src/options.cpp:155-172): the CLI default "--seed SMEM" is ALFA_SEED_SMAM. */
+#define ALFA_SEED_SMAM  0   /* sparseSA::SMAM   src/sparseSA.cpp:1121 */
+#define ALFA_SEED_MEM   1   /* sparseSA::MEM    src/sparseSA.cpp:1116 */
+#define ALFA_SEED_SMEM  2   /* sparseSA::SMEM   src/sparseSA.cpp:1127 */
+#define ALFA_SEED_SMEMP 3   /* sparseSA::SMEMP  src/sparseSA.cpp:1211 */
+
+/* == match_t (src/sparseSA.h:103-110): 16 bytes */
+typedef struct { int64_t ref; int32_t query; int32_t len; } alfa_match;
+
+/* Host view of the enhanced sparse suffix array, i.e. the public data members
+ * of `struct sparseSA` (src/sparseSA.h:142-163).  All arrays are borrowed.
+ * S must have at least 16 readable bytes after S[N-1] (the reference reads
+ * S[SA+depth] un-guarded into the terminator, src/sparseSA.cpp:775). */
+typedef struct {
+    const uint8_t*  S;          /* concatenated lower-case text + '`' separators + '$' padding */
+    int64_t         N;          /* S length (multiple of K) */
+    int64_t         K;          /* sparseness */
+    int64_t         logN;
+    int64_t         NKm1;       /* N/K - 1 */
+    const uint32_t* SA;         /* n = N/K sampled suffixes */
+    int64_t         n;
+    const uint8_t*  LCP;        /* vec_uchar::vec, 255 == look up overflow table */
+    const int64_t*  LCP_M_idx;  /* vec_uchar::M (sorted by idx), split into two arrays */
+    const int32_t*  LCP_M_val;
+    int64_t         nM;
+    const int32_t*  CHILD;      /* may be NULL when !has_child */
+    const int32_t*  ISA;        /* may be NULL when !has_suflink */
+    const uint32_t* KMR;        /* 2*4^10 words: (left,right) per 10-mer; NULL when !has_kmer */
+    int32_t         has_child, has_suflink, has_kmer;
+    int32_t         n_seq;      /* number of concatenated sequences */
+    const int64_t*  startpos;   /* n_seq start offsets in S */
+} alfa_index_view;
+
+/* one sparseSA::{SMAM,MEM,SMEM,SMEMP}(P, matches, min_len, maxCount, sparseQ[, max_smem_cont]) call */
+typedef struct {
+    const char* P;              /* read bases exactly as the reference sees them (lower-case ASCII) */
+    int32_t plen;
+    int32_t min_len;
+    int32_t max_count;
+    int32_t sparse_q;
+    int32_t max_smem_cont;      /* SMEM/SMEMP only */
+} alfa_seed_query;
+
+/* one ksw_{extend,nw,global}(qlen, query, tlen, target, m, mat, gapo, gape, w, ...) call */
+typedef struct {
+    const uint8_t* query;       /* nt4 codes 0..m-1 */
+    const uint8_t* target;
+    int32_t qlen, tlen;
+    int32_t w;                  /* band */
+    int32_t h0;                 /* ksw_extend only */
+} alfa_dp_task;
+
+typedef struct {
+    int32_t m;                  /* residue types (the reference always passes 5) */
+    int8_t  mat[64];            /* m*m scoring matrix, row-major (src/options.cpp:33-41) */
+    int32_t gapo, gape;         /* POSITIVE penalties, as the reference passes them (-1*openGap) */
+    int32_t zdrop;              /* ksw_extend only (100 at src/mapper.cpp:787,829) */
+} alfa_dp_params;
+
+/* outputs of ksw_extend: return value + *_qle,*_tle,*_gtle,*_gscore,*_max_off (src/ksw.c:442-447) */
+typedef struct { int32_t score, qle, tle, gtle, gscore, max_off; } alfa_extend_result;
+
+typedef struct alfa_index alfa_index;   /* opaque; owns the HBM-resident copy on one device */
+
+/* --- residency ---------------------------------------------------------- */
+/* replaces: sparseSA::load / construct leaving the arrays in host vectors
+ * (src/sparseSA.cpp:390-476, 478-558); here they are copied once into HBM
+ * (plus derived device layouts) and stay resident. */
+int  alfa_index_upload(const alfa_index_view* host_arrays, int device, alfa_index** out);
+void alfa_index_free(alfa_index*);
+int  alfa_index_device(const alfa_index*);
+
+/* --- seeds -------------------------------------------------------------- */
+/* replaces: executeSeedType -> sa.SMAM/MEM/SMEM/SMEMP(P, matches, ...)
+ * (src/mapper.cpp:519-528, src/sparseSA.h:274-283) for nq independent calls.
+ * *matches is library-allocated; query i owns (*matches)[offsets[i] .. offsets[i+1])
+ * in exactly the order the reference appends them; offsets has nq+1 entries
+ * (caller-allocated).  min_len < K is the reference's silent no-op. */
+int  alfa_seed_batch(alfa_index*, int mem_type, const alfa_seed_query* q, int nq,
+                     alfa_match** matches, int64_t* offsets);
+
+/* --- banded DP ---------------------------------------------------------- */
+/* replaces: ksw_extend(...)  src/ksw.h:106 / src/ksw.c:362 */
+int  alfa_ksw_extend_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, alfa_extend_result* r);
+/* replaces: ksw_nw(...)      src/ksw.h:83  / src/ksw.c:544 */
+int  alfa_ksw_nw_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, int32_t* score);
+/* replaces: ksw_global(...)  src/ksw.h:82  / src/ksw.c:468.  *cigar is library-allocated
+ * (BAM encoding len<<4|op, already in forward order); task i owns
+ * (*cigar)[cig_off[i] .. cig_off[i]+n_cigar[i]); cig_off has n+1 entries. */
+int  alfa_ksw_global_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, int32_t* score,
+                           uint32_t** cigar, int32_t* n_cigar, int64_t* cig_off);
+
+/* --- dynProg (dp.cpp) ---------------------------------------------------- */
+#define ALFA_DPBAND_STATIC 0   /* dynProg::dpBandStatic src/dp.cpp:648 */
+#define ALFA_DPBAND_FULL   1   /* dynProg::dpBandFull   src/dp.cpp:761 */
+#define ALFA_DPBAND_SCORE  2   /* dynProg::dpBandScore  src/dp.cpp:872 */
+#define ALFA_DPBAND_BASIC  3   /* dynProg::dpBasic      src/dp.cpp:926 */
+typedef struct {
+    const char* ref;  int64_t ref_len;       /* ASCII, as the reference's std::string */
+    const char* query; int64_t query_len;
+    int64_t refB, refE; int32_t queryB, queryE;   /* boundaries (src/dp.h:29-36) */
+    uint8_t freeRefB, freeRefE, freeQueryB, freeQueryE, local;  /* dp_type (src/dp.h:49-57) */
+    int32_t out_type;                        /* outputType (src/dp.h:68-74) */
+    int32_t band1, band2;                    /* minband,maxband | bandLeft,bandRight */
+} alfa_dpband_task;
+typedef struct { int32_t match, mismatch, openGap, extendGap; int32_t affine; } alfa_dpband_scores;
+typedef struct {
+    int32_t ret, dpScore, editDist;
+    int64_t refB, refE; int32_t queryB, queryE;   /* boundaries after the call */
+    int32_t n_cigar; int64_t cig_off;        /* run-length =XID ops in (*cig_chars,*cig_lens) */
+} alfa_dpband_result;
+int  alfa_dp_band_batch(int variant, const alfa_dpband_scores* s, const alfa_dpband_task* t, int n,
+                        alfa_dpband_result* r, char** cig_chars, int32_t** cig_lens);
+
+/* --- misc --------------------------------------------------------------- */
+void        alfa_free(void*);            /* every library-allocated host buffer */
+const char* alfa_last_error(void);       /* thread-local, human readable */
+int         alfa_device_count(void);     /* 0 when no HIP device is usable */
+
+/* per-kernel timing of the calling thread's most recent batch call, measured with
+ * HIP events on the library's own stream: kernel milliseconds, algorithmic work
+ * units (SA: bytes per SURVEY 8d; DP: inner-loop cells) -- used by bench.py. */
+typedef struct { double kernel_ms; double h2d_ms, d2h_ms; int64_t work_units; int32_t launches; } alfa_timing;
+int  alfa_last_timing(alfa_timing* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALFA_HOT_H */
