@@ -1,0 +1,63 @@
+// device_ctx.h -- per-host-thread HIP context of libalfa_hot: one stream, timing events and
+// growable device / pinned-host staging buffers that are reused from call to call.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "errors.h"
+
+namespace alfa {
+
+#define ALFA_HIP(expr)                                                                              \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return ::alfa::fail(ALFA_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);  // keeps contents undefined; returns ALFA_OK / error
+    void release();
+    template <class T> T* as() const { return (T*)p; }
+};
+// grow-only pinned host buffer
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct Timing {
+    double kernel_ms = 0, h2d_ms = 0, d2h_ms = 0;
+    int64_t work_units = 0;
+    int32_t launches = 0;
+};
+
+struct Ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // staging
+    DevBuf d_in, d_in2, d_tasks, d_out, d_out2, d_scratch, d_z, d_cnt, d_off, d_ivl;
+    PinBuf h_in, h_in2, h_tasks, h_out, h_out2;
+    Timing last;
+    int ensure(int dev);  // binds the calling thread to `dev` (creates stream/events on first use)
+};
+
+// timing of the calling thread's most recent batch call (alfa_last_timing)
+extern thread_local Timing g_last_timing;
+
+// the calling thread's context for `device`; nullptr + last error when HIP is unusable
+Ctx* thread_ctx(int device);
+// number of usable devices (0 when the runtime cannot be initialised)
+int device_count();
+
+}  // namespace alfa

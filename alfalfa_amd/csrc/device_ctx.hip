@@ -1,0 +1,87 @@
+// device_ctx.hip -- see device_ctx.h
+#include "device_ctx.h"
+
+#include <map>
+#include <memory>
+
+namespace alfa {
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return ALFA_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        return fail(ALFA_ENOMEM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+    }
+    cap = want;
+    return ALFA_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+}
+int PinBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return ALFA_OK;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        p = nullptr;
+        return fail(ALFA_ENOMEM, std::string("hipHostMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+    }
+    cap = want;
+    return ALFA_OK;
+}
+void PinBuf::release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+}
+
+int device_count() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int Ctx::ensure(int dev) {
+    int n = device_count();
+    if (n <= 0) return fail(ALFA_ENODEV, "no HIP device is usable; libalfa_hot has no CPU fallback");
+    if (dev < 0 || dev >= n) return fail(ALFA_EINVAL, "device ordinal out of range");
+    ALFA_HIP(hipSetDevice(dev));
+    if (!stream) {
+        device = dev;
+        ALFA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (auto& e : ev) ALFA_HIP(hipEventCreate(&e));
+    }
+    return ALFA_OK;
+}
+
+Ctx* thread_ctx(int device) {
+    // one context per (thread, device); contexts live until the thread exits
+    thread_local std::map<int, std::unique_ptr<Ctx>> ctxs;
+    auto& slot = ctxs[device];
+    if (!slot) slot.reset(new Ctx());
+    if (slot->ensure(device) != ALFA_OK) return nullptr;
+    return slot.get();
+}
+
+}  // namespace alfa
+
+extern "C" int alfa_device_count(void) { return alfa::device_count(); }
+
+namespace alfa { thread_local Timing g_last_timing; }
+
+extern "C" int alfa_last_timing(alfa_timing* out) {
+    if (!out) return alfa::fail(ALFA_EINVAL, "null argument");
+    out->kernel_ms = alfa::g_last_timing.kernel_ms;
+    out->h2d_ms = alfa::g_last_timing.h2d_ms;
+    out->d2h_ms = alfa::g_last_timing.d2h_ms;
+    out->work_units = alfa::g_last_timing.work_units;
+    out->launches = alfa::g_last_timing.launches;
+    return ALFA_OK;
+}
+
+extern "C" void alfa_free(void* p) { free(p); }

@@ -1,0 +1,65 @@
+"""GPU parity: the HIP banded-DP kernels (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from alfalfa_amd import ffi
+import oracle_ffi as O
+import dpgen
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp_global(g, c, pairs, ws):
+    sg, cg, ng, og = g
+    sc, cc, nc, oc = c
+    assert np.array_equal(sg, sc)
+    for i, (q, t) in enumerate(pairs):
+        if len(t) > len(q) + ws[i]:
+            # reference indexes outside its backtrack matrix here (unspecified): the library reports n_cigar=-1
+            assert ng[i] == -1
+            continue
+        assert ng[i] == nc[i], (i, len(q), len(t), ws[i])
+        assert np.array_equal(cg[og[i]:og[i] + ng[i]], cc[oc[i]:oc[i] + nc[i]]), (i, len(q), len(t), ws[i])
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_bag(gpu, seed):
+    pairs, ws, hs = dpgen.random_tasks(seed, 1500)
+    P = ffi.default_params()
+    tasks, keep = ffi.make_dp_tasks(pairs, ws, hs)
+    e = ffi.ksw_extend_batch(P, tasks)
+    eo = O.orc_ksw_extend_batch(P, tasks)
+    bad = np.nonzero(e != eo)[0]
+    assert len(bad) == 0, [(int(i), len(pairs[i][0]), len(pairs[i][1]), ws[i], hs[i], e[i], eo[i]) for i in bad[:5]]
+    n = ffi.ksw_nw_batch(P, tasks)
+    no = O.orc_ksw_nw_batch(P, tasks)
+    bad = np.nonzero(n != no)[0]
+    assert len(bad) == 0, [(int(i), len(pairs[i][0]), len(pairs[i][1]), ws[i], n[i], no[i]) for i in bad[:5]]
+    _cmp_global(ffi.ksw_global_batch(P, tasks), O.orc_ksw_global_batch(P, tasks), pairs, ws)
+
+
+@pytest.mark.parametrize("band,rl,err", [(21, 250, 0.02), (100, 1500, 0.1), (60, 700, 0.05)])
+def test_mapper_like(gpu, band, rl, err):
+    pairs, ws, hs = dpgen.mapper_like_tasks(7, 600, rl, err, band)
+    P = ffi.default_params()
+    tasks, keep = ffi.make_dp_tasks(pairs, ws, hs)
+    assert np.array_equal(ffi.ksw_extend_batch(P, tasks), O.orc_ksw_extend_batch(P, tasks))
+    assert np.array_equal(ffi.ksw_nw_batch(P, tasks), O.orc_ksw_nw_batch(P, tasks))
+    _cmp_global(ffi.ksw_global_batch(P, tasks), O.orc_ksw_global_batch(P, tasks), pairs, ws)
+
+
+def test_other_scoring(gpu):
+    pairs, ws, hs = dpgen.random_tasks(5, 600)
+    for (ma, mi, go, ge, zd) in [(2, -3, -5, -2, 50), (1, -1, -1, -1, 0), (3, -2, 0, -1, 20)]:
+        P = ffi.default_params(ma, mi, go, ge, zd)
+        tasks, keep = ffi.make_dp_tasks(pairs, ws, hs)
+        assert np.array_equal(ffi.ksw_extend_batch(P, tasks), O.orc_ksw_extend_batch(P, tasks))
+        assert np.array_equal(ffi.ksw_nw_batch(P, tasks), O.orc_ksw_nw_batch(P, tasks))
+        _cmp_global(ffi.ksw_global_batch(P, tasks), O.orc_ksw_global_batch(P, tasks), pairs, ws)
+
+
+def test_empty_batch(gpu):
+    P = ffi.default_params()
+    tasks, keep = ffi.make_dp_tasks([], 0, 0)
+    assert len(ffi.ksw_extend_batch(P, tasks)) == 0
+    assert len(ffi.ksw_nw_batch(P, tasks)) == 0
