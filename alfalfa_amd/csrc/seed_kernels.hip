@@ -1,0 +1,470 @@
+// seed_kernels.hip -- batched exact-match seed retrieval from the HBM-resident enhanced sparse
+// suffix array (SA + LCP + child table + 10-mer table), gfx950.
+//
+// Batch form of sparseSA::SMAM (src/sparseSA.cpp:1121-1124 -> findSMAM :1063-1114 ->
+// traverse_faster :733-791 -> top_down_child :671-697 -> collectAllSMAMs :901-907 ->
+// find_LmaximalStrict :858-871), the reference's default seed type (CLI "--seed SMEM").
+//
+// Work decomposition: the reference walks, for each phase k<K, the prefixes k, k+q*K, k+2q*K ...
+// of a read and (without suffix links, the default index) restarts from the root for every prefix,
+// so every (read, prefix) pair is an independent query.  One workgroup owns one read (one strand);
+// the read is staged once into LDS; each lane owns one prefix query at a time:
+//   10-mer table jump (8 B) -> child-table descent (CHILD/LCP/SA probes) -> edge walk against S
+// Results are produced deterministically in the reference's emission order without a global sort:
+//   kernel A  traverse + count the matches every query will emit, block-level exclusive scan gives
+//             the offset inside the read, emitting queries append a 24-byte record to a work list
+//   scan      exclusive sum of the per-read totals
+//   kernel B  one lane per work-list record re-enumerates its SA interval, left-extends
+//             (find_LmaximalStrict) and writes match_t records at base[read] + offset
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "device_ctx.h"
+
+struct alfa_index {
+    int device = 0;
+    int64_t N = 0, n = 0, K = 1, logN = 0, NKm1 = 0, nM = 0;
+    int has_child = 0, has_suflink = 0, has_kmer = 0;
+    alfa::DevBuf S, SA, LCP, Midx, Mval, CHILD, KMR;
+};
+
+namespace {
+
+constexpr int KMER = 10;
+constexpr uint32_t TABLE = 1u << (2 * KMER);
+constexpr int SEED_BLOCK = 128;
+
+struct DIdx {
+    const uint8_t* __restrict__ S;
+    const uint32_t* __restrict__ SA;
+    const uint8_t* __restrict__ LCP;
+    const int64_t* __restrict__ Midx;
+    const int32_t* __restrict__ Mval;
+    const int32_t* __restrict__ CHILD;
+    const uint2* __restrict__ KMR;
+    int64_t N;
+    int32_t n, nM, K, has_kmer;
+};
+
+struct SeedQ {          // one sparseSA::SMAM(P, ...) call
+    int64_t poff;       // offset of P in the packed read buffer
+    int32_t plen, min_len, max_count, sparse_q;
+    int32_t npref;      // number of prefix queries of this call
+    int32_t pad;
+};
+
+struct WorkRec {        // one emitting prefix query
+    int32_t read, woff, start, end, depth, prefix;
+};
+
+__device__ __forceinline__ uint32_t bitadd(uint32_t c) {
+    // sparseSA.h:38-63: a/A c/C g/G t/T -> 0..3, anything else all ones
+    c |= 0x20u;
+    return c == 'a' ? 0u : c == 'c' ? 1u : c == 'g' ? 2u : c == 't' ? 3u : 0xFFFFFFFFu;
+}
+
+__device__ __forceinline__ int d_child(const DIdx& X, int i) { return (i >= 0 && i < X.n) ? X.CHILD[i] : -1; }
+
+// vec_uchar::operator[] (sparseSA.h:79-84)
+__device__ __forceinline__ int d_lcp(const DIdx& X, int i) {
+    if (i < 0 || i >= X.n) return 0;
+    const uint32_t b = X.LCP[i];
+    if (b != 255u) return (int)b;
+    int lo = 0, hi = X.nM;   // lower_bound on the overflow table
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (X.Midx[mid] < (int64_t)i) lo = mid + 1; else hi = mid;
+    }
+    return X.Mval[lo];
+}
+
+__device__ __forceinline__ uint32_t d_s(const DIdx& X, int64_t pos) { return (pos >= 0 && pos < X.N + 16) ? X.S[pos] : 0u; }
+
+struct PatD {           // read staged in LDS; out-of-range reads give '\0' like std::string::operator[](size())
+    const uint8_t* p;
+    int len;
+    __device__ __forceinline__ uint32_t at(int i) const { return (i >= 0 && i < len) ? p[i] : 0u; }
+};
+
+// lcp-interval value of [start,end]  (sparseSA.cpp:751-754, 768-771)
+__device__ __forceinline__ int ival_lcp(const DIdx& X, int start, int end) {
+    const int ce = d_child(X, end);
+    if (start < ce && ce <= end) return d_lcp(X, ce);
+    return d_lcp(X, d_child(X, start));
+}
+
+// top_down_child  sparseSA.cpp:671-697
+__device__ bool td_child(const DIdx& X, uint32_t c, int& start, int& end, int depth) {
+    int left = start;
+    int right = d_child(X, end);
+    if (start >= right || right > end) right = d_child(X, start);
+    if (d_s(X, (int64_t)X.SA[start] + depth) == c) { end = right - 1; return true; }
+    left = right;
+    for (;;) {
+        const int nxt = d_child(X, right);
+        if (!(nxt > right && d_lcp(X, right) == d_lcp(X, nxt))) break;
+        right = nxt;
+        if (d_s(X, (int64_t)X.SA[left] + depth) == c) { start = left; end = right - 1; return true; }
+        left = right;
+    }
+    if (d_s(X, (int64_t)X.SA[left] + depth) == c) { start = left; return true; }
+    return false;
+}
+
+// traverse_faster  sparseSA.cpp:733-791 with maxBranching = -1 (the only value the reference passes)
+__device__ void traverse_child(const DIdx& X, const PatD& P, int prefix, int& start, int& end, int& depth, int min_len) {
+    if (X.has_kmer && depth == 0 && min_len >= KMER) {
+        uint32_t index = 0;
+#pragma unroll
+        for (int i = 0; i < KMER; ++i) index = (index << 2) | bitadd(P.at(prefix + i));
+        if (index >= TABLE) return;
+        const uint2 lr = X.KMR[index];
+        if (lr.y == 0) return;
+        depth = KMER; start = (int)lr.x; end = (int)lr.y;
+    }
+    if (depth >= min_len) return;
+    int c = prefix + depth;
+    bool found = c < P.len;
+    if (found) {
+        if (end > start && ival_lcp(X, start, end) == depth) found = td_child(X, P.at(c), start, end, depth);
+        else found = P.at(c) == d_s(X, (int64_t)X.SA[start] + depth);
+    }
+    bool mism = false;
+    while (found && !mism && c < P.len && depth < min_len) {
+        ++c; ++depth;
+        if (start != end) {
+            const int childLCP = ival_lcp(X, start, end);
+            const int minimum = childLCP < min_len ? childLCP : min_len;
+            const int64_t sp = (int64_t)X.SA[start];
+            while (!mism && c < P.len && depth < minimum) {
+                mism = d_s(X, sp + depth) != P.at(c);
+                ++c; depth += !mism;
+            }
+            found = c < P.len && !mism && depth < min_len && td_child(X, P.at(c), start, end, depth);
+        } else {
+            const int64_t sp = (int64_t)X.SA[start];
+            while (!mism && c < P.len && depth < min_len) {
+                const int64_t pos = sp + depth;
+                mism = pos >= X.N || d_s(X, pos) != P.at(c);
+                ++c; depth += !mism;
+            }
+        }
+    }
+}
+
+// find_LmaximalStrict  sparseSA.cpp:858-871.  Returns true (and the match) when one is emitted.
+template <class PAT>
+__device__ __forceinline__ bool lmax_strict(const DIdx& X, const PAT& P, int prefix, int64_t i, int len, int min_len, int border,
+                                            int64_t& mref, int& mq, int& mlen) {
+    for (int k = 0; k < border; ++k) {
+        if (prefix == 0 || i == 0 || P.at(prefix - 1) != d_s(X, i - 1)) {
+            if (len >= min_len) { mref = i; mq = prefix; mlen = len; return true; }
+            return false;
+        }
+        --prefix; --i; ++len;
+    }
+    return false;
+}
+
+// flat reference-order index t -> (phase k, step jj) of findSMAM's double loop
+struct PrefixMap {
+    int step, nh, kh, Lmax;
+    __device__ __forceinline__ int prefix_of(int t) const {
+        int k, jj;
+        if (t < kh * nh) { k = t / nh; jj = t - k * nh; }
+        else { const int t2 = t - kh * nh; const int q = t2 / (nh - 1); k = kh + q; jj = t2 - q * (nh - 1); }
+        return k + jj * step;
+    }
+};
+
+// block-wide exclusive scan of one int per thread (SEED_BLOCK threads); total returned to every thread
+__device__ __forceinline__ int block_excl_scan(int v, int* sh, int& total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) sh[wid] = inc;
+    __syncthreads();
+    int base = 0;
+    constexpr int NW = SEED_BLOCK / 64;
+    int tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { const int s = sh[i]; if (i < wid) base += s; tot += s; }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+// ---------------------------------------------------------------- kernel A: traverse + count
+__global__ __launch_bounds__(SEED_BLOCK) void smam_count_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
+                                                               int64_t* __restrict__ read_total, WorkRec* __restrict__ work,
+                                                               int* __restrict__ work_count, int work_cap, int lds_p) {
+    extern __shared__ uint8_t smem[];
+    __shared__ int sh_scan[SEED_BLOCK / 64];
+    const int r = blockIdx.x;
+    const SeedQ Q = qs[r];
+    const int tid = threadIdx.x;
+    PatD P;
+    P.len = Q.plen;
+    if (lds_p) {
+        for (int i = tid; i < Q.plen; i += SEED_BLOCK) smem[i] = reads[Q.poff + i];
+        __syncthreads();
+        P.p = smem;
+    } else {
+        P.p = reads + Q.poff;
+    }
+    const int K = X.K;
+    const int step = Q.sparse_q * K;
+    const int min_lenK = Q.min_len - (step - 1);
+    const int minMin_len = Q.sparse_q > 1 ? Q.min_len - K : Q.min_len;
+    PrefixMap pm;
+    pm.step = step;
+    pm.Lmax = Q.plen - min_lenK;
+    pm.nh = pm.Lmax >= 0 ? pm.Lmax / step + 1 : 0;
+    {
+        const int kk = K < pm.Lmax + 1 ? K : pm.Lmax + 1;
+        const int r0 = pm.Lmax >= 0 ? pm.Lmax % step : 0;
+        pm.kh = kk < r0 + 1 ? kk : r0 + 1;
+    }
+    const int maxCount = Q.sparse_q * Q.max_count;
+    const int border = step;
+    int running = 0;
+    for (int base = 0; base < Q.npref; base += SEED_BLOCK) {
+        const int t = base + tid;
+        int cnt = 0, start = 0, end = X.n - 1, depth = 0, prefix = 0;
+        if (t < Q.npref) {
+            prefix = pm.prefix_of(t);
+            traverse_child(X, P, prefix, start, end, depth, Q.plen);
+            if (depth > 1 && depth >= min_lenK && (end - start + 1) <= maxCount) {
+                for (int i = start; i <= end; ++i) {
+                    int64_t mr; int mq, ml;
+                    cnt += lmax_strict(X, P, prefix, (int64_t)X.SA[i], depth, minMin_len, border, mr, mq, ml) ? 1 : 0;
+                }
+            }
+        }
+        int total;
+        const int excl = block_excl_scan(cnt, sh_scan, total);
+        if (cnt > 0) {
+            const int slot = atomicAdd(work_count, 1);
+            if (slot < work_cap) {
+                WorkRec w;
+                w.read = r; w.woff = running + excl; w.start = start; w.end = end; w.depth = depth; w.prefix = prefix;
+                work[slot] = w;
+            }
+        }
+        running += total;
+    }
+    if (tid == 0) read_total[r] = running;
+}
+
+struct PatG {   // read bytes straight from global memory (kernel B touches only a few of them)
+    const uint8_t* p;
+    int len;
+    __device__ __forceinline__ uint32_t at(int i) const { return (i >= 0 && i < len) ? p[i] : 0u; }
+};
+
+// ---------------------------------------------------------------- kernel B: emit
+__global__ void smam_emit_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
+                                 const int64_t* __restrict__ read_base, const WorkRec* __restrict__ work, int nwork,
+                                 alfa_match* __restrict__ out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nwork) return;
+    const WorkRec w = work[g];
+    const SeedQ Q = qs[w.read];
+    PatG P; P.p = reads + Q.poff; P.len = Q.plen;
+    const int K = X.K;
+    const int minMin_len = Q.sparse_q > 1 ? Q.min_len - K : Q.min_len;
+    const int border = Q.sparse_q * K;
+    alfa_match* o = out + read_base[w.read] + w.woff;
+    for (int i = w.start; i <= w.end; ++i) {
+        int64_t mr; int mq, ml;
+        if (lmax_strict(X, P, w.prefix, (int64_t)X.SA[i], w.depth, minMin_len, border, mr, mq, ml)) {
+            alfa_match m; m.ref = mr; m.query = mq; m.len = ml;
+            *o++ = m;
+        }
+    }
+}
+
+// number of prefix queries of one SMAM call (mirrors findSMAM's loop bounds, sparseSA.cpp:1066-1072)
+int64_t count_prefixes(int64_t K, int plen, int min_len, int sparse_q) {
+    if (min_len < K) return 0;                       // sparseSA.cpp:1122
+    const int64_t step = (int64_t)sparse_q * K;
+    if (step <= 0) return -1;
+    const int64_t min_lenK = min_len - (step - 1);
+    const int64_t L = (int64_t)plen - min_lenK;
+    int64_t tot = 0;
+    for (int64_t k = 0; k < K && k <= L; ++k) tot += (L - k) / step + 1;
+    return tot;
+}
+
+int upload(alfa::DevBuf& b, const void* src, size_t bytes, size_t pad = 0) {
+    int rc = b.reserve(bytes + pad + 16);
+    if (rc) return rc;
+    if (bytes) ALFA_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    if (pad) ALFA_HIP(hipMemset((char*)b.p + bytes, 0, pad));
+    return ALFA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int alfa_index_upload(const alfa_index_view* v, int device, alfa_index** out) {
+    if (!v || !out) return alfa::fail(ALFA_EINVAL, "null argument");
+    if (!v->S || !v->SA || !v->LCP || v->n <= 0) return alfa::fail(ALFA_EINVAL, "incomplete index view");
+    if (v->n >= 0x7fffffffLL) return alfa::fail(ALFA_EINVAL, "index too large for int32 SA ranks");
+    alfa::Ctx* cx = alfa::thread_ctx(device);
+    if (!cx) return ALFA_ENODEV;
+    alfa_index* ix = new alfa_index();
+    ix->device = device;
+    ix->N = v->N; ix->n = v->n; ix->K = v->K; ix->logN = v->logN; ix->NKm1 = v->NKm1; ix->nM = v->nM;
+    ix->has_child = v->has_child && v->CHILD; ix->has_suflink = v->has_suflink; ix->has_kmer = v->has_kmer && v->KMR;
+    int rc = ALFA_OK;
+    if ((rc = upload(ix->S, v->S, (size_t)v->N, 32)) || (rc = upload(ix->SA, v->SA, 4 * (size_t)v->n)) ||
+        (rc = upload(ix->LCP, v->LCP, (size_t)v->n)) || (rc = upload(ix->Midx, v->LCP_M_idx, 8 * (size_t)v->nM)) ||
+        (rc = upload(ix->Mval, v->LCP_M_val, 4 * (size_t)v->nM)) ||
+        (ix->has_child && (rc = upload(ix->CHILD, v->CHILD, 4 * (size_t)v->n))) ||
+        (ix->has_kmer && (rc = upload(ix->KMR, v->KMR, 8 * (size_t)TABLE)))) {
+        alfa_index_free(ix);
+        return rc;
+    }
+    *out = ix;
+    return ALFA_OK;
+}
+
+void alfa_index_free(alfa_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    ix->S.release(); ix->SA.release(); ix->LCP.release(); ix->Midx.release(); ix->Mval.release(); ix->CHILD.release(); ix->KMR.release();
+    delete ix;
+}
+
+int alfa_index_device(const alfa_index* ix) { return ix ? ix->device : -1; }
+
+int alfa_seed_batch(alfa_index* ix, int mem_type, const alfa_seed_query* q, int nq, alfa_match** matches, int64_t* offsets) {
+    alfa::g_last_timing = alfa::Timing();
+    if (!ix || !matches || !offsets || nq < 0 || (nq > 0 && !q)) return alfa::fail(ALFA_EINVAL, "null argument");
+    if (mem_type != ALFA_SEED_SMAM)
+        return alfa::fail(ALFA_ENOTSUP, "only ALFA_SEED_SMAM (the reference's default seed type) has a HIP kernel so far");
+    if (!ix->has_child) return alfa::fail(ALFA_ENOTSUP, "the HIP seed kernels need an index with a child table (--no-child unsupported)");
+    if (ix->has_suflink) return alfa::fail(ALFA_ENOTSUP, "suffix-link (--suflink) indexes are not supported by the HIP seed kernels");
+    alfa::Ctx* cx = alfa::thread_ctx(ix->device);
+    if (!cx) return ALFA_ENODEV;
+    *matches = nullptr;
+    offsets[0] = 0;
+    if (nq == 0) { *matches = (alfa_match*)malloc(sizeof(alfa_match)); return ALFA_OK; }
+
+    // ---- pack reads + query descriptors
+    size_t bytes = 0;
+    int max_plen = 0;
+    for (int i = 0; i < nq; ++i) {
+        if (q[i].plen < 0 || (q[i].plen > 0 && !q[i].P)) return alfa::fail(ALFA_EINVAL, "bad read in seed query");
+        if (q[i].sparse_q < 1) return alfa::fail(ALFA_EINVAL, "sparse_q must be >= 1");
+        bytes += (size_t)q[i].plen;
+        max_plen = std::max(max_plen, q[i].plen);
+    }
+    int rc;
+    if ((rc = cx->h_in.reserve(bytes + 64)) || (rc = cx->h_tasks.reserve(sizeof(SeedQ) * (size_t)nq)) ||
+        (rc = cx->d_in.reserve(bytes + 64)) || (rc = cx->d_tasks.reserve(sizeof(SeedQ) * (size_t)nq)) ||
+        (rc = cx->d_cnt.reserve(8 * ((size_t)nq + 1) + 64)) || (rc = cx->d_off.reserve(8 * ((size_t)nq + 1) + 64)))
+        return rc;
+    uint8_t* hp = cx->h_in.as<uint8_t>();
+    SeedQ* hq = cx->h_tasks.as<SeedQ>();
+    size_t po = 0;
+    int64_t total_pref = 0;
+    for (int i = 0; i < nq; ++i) {
+        SeedQ& s = hq[i];
+        s.poff = (int64_t)po;
+        s.plen = q[i].plen; s.min_len = q[i].min_len; s.max_count = q[i].max_count; s.sparse_q = q[i].sparse_q;
+        const int64_t np = count_prefixes(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q);
+        if (np < 0 || np > 0x7fffffff) return alfa::fail(ALFA_EINVAL, "seed query has too many prefixes");
+        s.npref = (int32_t)np;
+        s.pad = 0;
+        total_pref += np;
+        if (q[i].plen) memcpy(hp + po, q[i].P, (size_t)q[i].plen);
+        po += (size_t)q[i].plen;
+    }
+    DIdx X;
+    X.S = ix->S.as<uint8_t>(); X.SA = ix->SA.as<uint32_t>(); X.LCP = ix->LCP.as<uint8_t>();
+    X.Midx = ix->Midx.as<int64_t>(); X.Mval = ix->Mval.as<int32_t>(); X.CHILD = ix->CHILD.as<int32_t>();
+    X.KMR = ix->KMR.as<uint2>();
+    X.N = ix->N; X.n = (int32_t)ix->n; X.nM = (int32_t)ix->nM; X.K = (int32_t)ix->K; X.has_kmer = ix->has_kmer;
+
+    hipStream_t st = cx->stream;
+    const int lds_p = max_plen <= 48 * 1024;
+    const size_t lds_bytes = lds_p ? (size_t)max_plen + 16 : 0;
+    ALFA_HIP(hipEventRecord(cx->ev[0], st));
+    ALFA_HIP(hipMemcpyAsync(cx->d_in.p, hp, bytes, hipMemcpyHostToDevice, st));
+    ALFA_HIP(hipMemcpyAsync(cx->d_tasks.p, hq, sizeof(SeedQ) * (size_t)nq, hipMemcpyHostToDevice, st));
+    int64_t* d_tot = cx->d_cnt.as<int64_t>();
+    int64_t* d_base = cx->d_off.as<int64_t>();
+    // work list: grows (and the count kernel is re-run) only if the first guess overflows
+    int work_cap = (int)std::min<int64_t>(std::max<int64_t>(4096, 4 * (int64_t)nq), std::max<int64_t>(total_pref, 1));
+    int nwork = 0;
+    float ms_kernel = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = cx->d_ivl.reserve(sizeof(WorkRec) * (size_t)work_cap + 64))) return rc;
+        int* d_wc = (int*)((char*)cx->d_ivl.p + sizeof(WorkRec) * (size_t)work_cap);
+        ALFA_HIP(hipMemsetAsync(d_wc, 0, 4, st));
+        ALFA_HIP(hipMemsetAsync(d_tot + nq, 0, 8, st));
+        ALFA_HIP(hipEventRecord(cx->ev[1], st));
+        hipLaunchKernelGGL(smam_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, cx->d_tasks.as<SeedQ>(), cx->d_in.as<uint8_t>(),
+                           d_tot, cx->d_ivl.as<WorkRec>(), d_wc, work_cap, lds_p);
+        ALFA_HIP(hipGetLastError());
+        ALFA_HIP(hipEventRecord(cx->ev[2], st));
+        ALFA_HIP(hipMemcpyAsync(&nwork, d_wc, 4, hipMemcpyDeviceToHost, st));
+        ALFA_HIP(hipStreamSynchronize(st));
+        float ms = 0;
+        ALFA_HIP(hipEventElapsedTime(&ms, cx->ev[1], cx->ev[2]));
+        ms_kernel += ms;
+        alfa::g_last_timing.launches += 1;
+        if (nwork <= work_cap) break;
+        work_cap = nwork;
+    }
+    {
+        float ms = 0;
+        ALFA_HIP(hipEventElapsedTime(&ms, cx->ev[0], cx->ev[1]));
+        alfa::g_last_timing.h2d_ms = ms;
+    }
+    // ---- exclusive scan of per-read totals (nq+1 items so that base[nq] = grand total)
+    size_t tmp_bytes = 0;
+    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_tot, d_base, nq + 1, st));
+    if ((rc = cx->d_scratch.reserve(tmp_bytes + 64))) return rc;
+    ALFA_HIP(hipEventRecord(cx->ev[1], st));
+    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(cx->d_scratch.p, tmp_bytes, d_tot, d_base, nq + 1, st));
+    ALFA_HIP(hipMemcpyAsync(offsets, d_base, 8 * ((size_t)nq + 1), hipMemcpyDeviceToHost, st));
+    ALFA_HIP(hipStreamSynchronize(st));
+    const int64_t total = offsets[nq];
+    alfa_match* hm = (alfa_match*)malloc(sizeof(alfa_match) * (size_t)(total + 1));
+    if (!hm) return alfa::fail(ALFA_ENOMEM, "out of host memory for the match array");
+    if (total > 0) {
+        if ((rc = cx->d_out.reserve(sizeof(alfa_match) * (size_t)total))) { free(hm); return rc; }
+        hipLaunchKernelGGL(smam_emit_kernel, dim3((nwork + 127) / 128), dim3(128), 0, st, X, cx->d_tasks.as<SeedQ>(), cx->d_in.as<uint8_t>(),
+                           d_base, cx->d_ivl.as<WorkRec>(), nwork, cx->d_out.as<alfa_match>());
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { free(hm); return alfa::fail(ALFA_EHIP, hipGetErrorString(e)); }
+    }
+    ALFA_HIP(hipEventRecord(cx->ev[2], st));
+    if (total > 0) ALFA_HIP(hipMemcpyAsync(hm, cx->d_out.p, sizeof(alfa_match) * (size_t)total, hipMemcpyDeviceToHost, st));
+    ALFA_HIP(hipEventRecord(cx->ev[3], st));
+    ALFA_HIP(hipStreamSynchronize(st));
+    {
+        float ms = 0;
+        ALFA_HIP(hipEventElapsedTime(&ms, cx->ev[1], cx->ev[2]));
+        ms_kernel += ms;
+        ALFA_HIP(hipEventElapsedTime(&ms, cx->ev[2], cx->ev[3]));
+        alfa::g_last_timing.d2h_ms = ms;
+    }
+    alfa::g_last_timing.kernel_ms = ms_kernel;
+    alfa::g_last_timing.work_units = total_pref;
+    *matches = hm;
+    return ALFA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+"""GPU parity: the HIP SMAM seed kernels (through the C ABI) vs the CPU oracle, bit-exact and in order."""
+import numpy as np
+import pytest
+
+from alfalfa_amd import ffi
+import oracle_ffi as O
+import seqgen
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(hidx, didx, reads, min_len, max_count, sq):
+    q = ffi.make_seed_queries(reads, min_len, max_count, sq)
+    mg, og = didx.seed_batch(ffi.SEED_SMAM, q)
+    mc, oc = O.orc_seed_batch(hidx.view, ffi.SEED_SMAM, q)
+    assert np.array_equal(og, oc), "per-read offsets differ"
+    assert np.array_equal(mg, mc), "matches differ"
+    return len(mg)
+
+
+@pytest.mark.parametrize("K", [1, 3, 12])
+def test_smam_random_ref(gpu, K):
+    rng = np.random.default_rng(100 + K)
+    ref = seqgen.rand_ref(rng, 300000)
+    hidx = ffi.HostIndex.build_mem(["chr1"], [ref], K=K)
+    didx = ffi.DeviceIndex(hidx, gpu)
+    reads = seqgen.sim_reads(rng, ref, 400, 100, 400, 0.03)
+    reads += [b"", b"acgt", b"n" * 60, reads[0][:50] + b"n" + reads[0][50:]]
+    ml = [seqgen.seed_params(K, len(r))[0] for r in reads]
+    sq = [seqgen.seed_params(K, len(r))[1] for r in reads]
+    n = _check(hidx, didx, reads, ml, 10000, sq)
+    assert n > 300
+    # rescue parameters of the mapper (src/mapper.cpp:544-553) and a tiny maxCount
+    _check(hidx, didx, reads, max(20, K + 10), 100000, 1)
+    _check(hidx, didx, reads, 25, 3, 1)
+
+
+def test_smam_long_reads(gpu):
+    rng = np.random.default_rng(3)
+    ref = seqgen.rand_ref(rng, 1000000)
+    hidx = ffi.HostIndex.build_mem(["chr1"], [ref], K=12)
+    didx = ffi.DeviceIndex(hidx, gpu)
+    reads = seqgen.sim_reads(rng, ref, 60, 2000, 10000, 0.10)
+    ml = [seqgen.seed_params(12, len(r), 0.13)[0] for r in reads]
+    sq = [seqgen.seed_params(12, len(r), 0.13)[1] for r in reads]
+    assert _check(hidx, didx, reads, ml, 10000, sq) > 50
+
+
+def test_smam_repeats_multi_contig(gpu):
+    rng = np.random.default_rng(4)
+    a = seqgen.rand_ref(rng, 50000)
+    b = seqgen.rand_ref(rng, 20000)
+    c = a[2000:6000] + b"n" * 20 + b[100:3100] + b"acgt" * 200 + a[2000:6000] + b"a" * 900
+    names, seqs = ["a", "b", "c"], [a, b, c]
+    for K in (1, 4, 12):
+        hidx = ffi.HostIndex.build_mem(names, seqs, K=K)
+        didx = ffi.DeviceIndex(hidx, gpu)
+        cat = b"a".join(seqs)
+        reads = seqgen.sim_reads(rng, cat, 300, 60, 900, 0.02)
+        reads += [b"acgt" * 60, b"a" * 300, c[3990:4300]]
+        ml, sq = 40, seqgen.seed_params(K, 250)[1]
+        assert _check(hidx, didx, reads, ml, 10000, sq) > 100
+        _check(hidx, didx, reads, 25, 2, 1)
+
+
+def test_unsupported_types_fail_loudly(gpu):
+    rng = np.random.default_rng(5)
+    ref = seqgen.rand_ref(rng, 20000)
+    hidx = ffi.HostIndex.build_mem(["x"], [ref], K=3, suflink=True)
+    didx = ffi.DeviceIndex(hidx, gpu)
+    with pytest.raises(ffi.AlfaError):
+        didx.seed_batch(ffi.SEED_SMAM, ffi.make_seed_queries([ref[:100]], 40, 100, 1))
