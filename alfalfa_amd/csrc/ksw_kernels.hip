@@ -482,13 +482,24 @@ __global__ void ksw_scalar_kernel(const DevTask* __restrict__ tasks, int ntask, 
 }  // namespace
 
 // ================================================================= host side
+struct alfa_dp_batch {
+    int mode = 0, n = 0, device = 0;
+    DevParams hp;
+    std::vector<DevTask> ht;        // device order, .orig already remapped to the dense output index
+    std::vector<int> dense_of;      // device order -> caller index
+    int bin_cnt[4] = {0, 0, 0, 0};  // C=1, C=2, C=4, scalar
+    int64_t cig_words = 0, cells = 0, zbytes = 0, eh_items = 0;
+    size_t seq_bytes = 0, out_bytes = 0;
+    alfa::DevBuf d_seq, d_tasks, d_out, d_z, d_cig, d_eh;
+    alfa::PinBuf h_out, h_cig;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool launched = false;
+    double kernel_ms = 0;
+};
+
 namespace {
 
 using alfa::Ctx;
-
-struct Bins {
-    std::vector<int> idx[4];   // 0:C1 1:C2 2:C4 3:scalar
-};
 
 int pack_params(const alfa_dp_params* p, DevParams* dp) {
     if (!p) return alfa::fail(ALFA_EINVAL, "null scoring parameters");
@@ -498,166 +509,6 @@ int pack_params(const alfa_dp_params* p, DevParams* dp) {
     for (int t = 0; t < p->m; ++t)
         for (int q = 0; q < p->m; ++q) dp->matrow[t] |= (uint64_t)(uint8_t)p->mat[t * p->m + q] << (8 * q);
     dp->m = p->m; dp->gapo = p->gapo; dp->gape = p->gape; dp->zdrop = p->zdrop;
-    return ALFA_OK;
-}
-
-template <int MODE, int C>
-void launch_wave(Ctx* cx, const DevTask* d_tasks, int n, const uint8_t* d_seq, const DevParams* d_prm, int32_t* d_out, uint8_t* d_z) {
-    if (n <= 0) return;
-    dim3 grid((n + WPB - 1) / WPB), block(64 * WPB);
-    hipLaunchKernelGGL((ksw_wave_kernel<MODE, C>), grid, block, 0, cx->stream, d_tasks, n, d_seq, d_prm, d_out, d_z);
-}
-
-// Runs tasks[lo,hi) (already validated).  out: MODE_EXTEND -> ExtOut[n] indexed by orig, else int32 score[n].
-// GLOBAL additionally fills cigs (per-task vectors).
-template <int MODE>
-int run_range(Ctx* cx, const DevParams& hp, const alfa_dp_task* t, const int* w_eff, const std::vector<int>& ids, void* out_host,
-              std::vector<std::vector<uint32_t>>* cigs, int32_t* ncig_host, int64_t* cells_out) {
-    const int n = (int)ids.size();
-    if (n == 0) return ALFA_OK;
-    // ---- classify + order (longest targets first so that co-resident waves finish together)
-    std::vector<int> order(ids);
-    auto bin_of = [&](int id) {
-        const alfa_dp_task& x = t[id];
-        if (x.qlen == 0 || x.tlen == 0) return 3;
-        const int W = 2 * w_eff[id] + 1;
-        return W <= 64 ? 0 : W <= 128 ? 1 : W <= 256 ? 2 : 3;
-    };
-    std::vector<int> bins(n);
-    for (int i = 0; i < n; ++i) bins[i] = bin_of(order[i]);
-    std::vector<int> perm(n);
-    std::iota(perm.begin(), perm.end(), 0);
-    std::sort(perm.begin(), perm.end(), [&](int a, int b) {
-        if (bins[a] != bins[b]) return bins[a] < bins[b];
-        return t[order[a]].tlen > t[order[b]].tlen;
-    });
-    int bin_cnt[4] = {0, 0, 0, 0};
-    for (int i = 0; i < n; ++i) bin_cnt[bins[i]]++;
-
-    // ---- pack sequences and descriptors
-    size_t seq_bytes = 0;
-    for (int i = 0; i < n; ++i) seq_bytes += (size_t)t[order[i]].qlen + (size_t)t[order[i]].tlen;
-    int rc;
-    if ((rc = cx->h_in.reserve(seq_bytes + 64)) || (rc = cx->h_tasks.reserve(sizeof(DevTask) * (size_t)n + sizeof(DevParams))) ||
-        (rc = cx->d_in.reserve(seq_bytes + 64)) || (rc = cx->d_tasks.reserve(sizeof(DevTask) * (size_t)n + sizeof(DevParams))))
-        return rc;
-    uint8_t* hs = cx->h_in.as<uint8_t>();
-    DevParams* hprm = cx->h_tasks.as<DevParams>();
-    DevTask* ht = (DevTask*)(hprm + 1);
-    *hprm = hp;
-    size_t so = 0;
-    int64_t zbytes = 0, cig_words = 0, eh_items = 0, cells = 0;
-    const int Cs[4] = {1, 2, 4, 0};
-    for (int k = 0; k < n; ++k) {
-        const int id = order[perm[k]];
-        const int b = bins[perm[k]];
-        const alfa_dp_task& x = t[id];
-        DevTask& d = ht[k];
-        memset(&d, 0, sizeof(d));
-        d.qoff = (int64_t)so;
-        for (int j = 0; j < x.qlen; ++j) { uint8_t c = x.query[j]; if (c >= hp.m) return alfa::fail(ALFA_EINVAL, "query residue code >= m"); hs[so + j] = c; }
-        so += (size_t)x.qlen;
-        d.toff = (int64_t)so;
-        for (int j = 0; j < x.tlen; ++j) { uint8_t c = x.target[j]; if (c >= hp.m) return alfa::fail(ALFA_EINVAL, "target residue code >= m"); hs[so + j] = c; }
-        so += (size_t)x.tlen;
-        d.qlen = x.qlen; d.tlen = x.tlen; d.w = w_eff[id]; d.h0 = x.h0; d.orig = id;
-        if (b == 3) { d.ehoff = eh_items; eh_items += (int64_t)x.qlen + 2; }
-        if (MODE == MODE_GLOBAL) {
-            d.zoff = zbytes;
-            if (b == 3) { const int64_t ncol = std::min<int64_t>(x.qlen, 2 * (int64_t)d.w + 1); zbytes += ncol * x.tlen; }
-            else zbytes += (int64_t)x.tlen * 64 * Cs[b];
-            zbytes = (zbytes + 15) & ~(int64_t)15;
-            d.cigoff = cig_words;
-            d.cigcap = x.qlen + x.tlen + 2;
-            cig_words += d.cigcap;
-        }
-        // algorithmic cells: inner-loop iterations of the static band; EXTEND counts the same envelope
-        {
-            const int64_t w = d.w;
-            for (int i = 0; i < x.tlen; ++i) {
-                int64_t b0 = i > w ? i - w : 0, e0 = std::min<int64_t>(i + w + 1, x.qlen);
-                if (e0 > b0) cells += e0 - b0;
-            }
-        }
-    }
-    if (cells_out) *cells_out += cells;
-    const size_t out_bytes = (MODE == MODE_EXTEND ? sizeof(ExtOut) : sizeof(int32_t)) * (size_t)n;
-    if ((rc = cx->d_out.reserve(out_bytes)) || (rc = cx->h_out.reserve(out_bytes))) return rc;
-    if (eh_items && (rc = cx->d_scratch.reserve(sizeof(int2) * (size_t)eh_items))) return rc;
-    if (MODE == MODE_GLOBAL) {
-        if ((rc = cx->d_z.reserve((size_t)zbytes + 64)) || (rc = cx->d_out2.reserve(4 * (size_t)cig_words + 4 * (size_t)n)) ||
-            (rc = cx->h_out2.reserve(4 * (size_t)cig_words + 4 * (size_t)n)))
-            return rc;
-    }
-    // out buffers are indexed by `orig` relative to the caller's array: remap to dense 0..n-1 for this range
-    // (orig was set to the caller's index; we need a dense index for device output)
-    std::vector<int> dense_of(n);
-    for (int k = 0; k < n; ++k) { dense_of[k] = ht[k].orig; ht[k].orig = k; }
-
-    hipStream_t st = cx->stream;
-    ALFA_HIP(hipEventRecord(cx->ev[0], st));
-    ALFA_HIP(hipMemcpyAsync(cx->d_in.p, hs, seq_bytes, hipMemcpyHostToDevice, st));
-    ALFA_HIP(hipMemcpyAsync(cx->d_tasks.p, hprm, sizeof(DevParams) + sizeof(DevTask) * (size_t)n, hipMemcpyHostToDevice, st));
-    const DevParams* d_prm = cx->d_tasks.as<DevParams>();
-    const DevTask* d_t = (const DevTask*)(d_prm + 1);
-    const uint8_t* d_seq = cx->d_in.as<uint8_t>();
-    int32_t* d_out = cx->d_out.as<int32_t>();
-    uint8_t* d_z = cx->d_z.as<uint8_t>();
-    uint32_t* d_cig = cx->d_out2.as<uint32_t>();
-    int32_t* d_ncig = MODE == MODE_GLOBAL ? (int32_t*)(d_cig + cig_words) : nullptr;
-    ALFA_HIP(hipEventRecord(cx->ev[1], st));
-    int o = 0;
-    launch_wave<MODE, 1>(cx, d_t + o, bin_cnt[0], d_seq, d_prm, d_out, d_z);
-    if (MODE == MODE_GLOBAL && bin_cnt[0])
-        hipLaunchKernelGGL((ksw_backtrack_kernel<1>), dim3((bin_cnt[0] + 63) / 64), dim3(64), 0, st, d_t + o, bin_cnt[0], d_z, d_cig, d_ncig);
-    o += bin_cnt[0];
-    launch_wave<MODE, 2>(cx, d_t + o, bin_cnt[1], d_seq, d_prm, d_out, d_z);
-    if (MODE == MODE_GLOBAL && bin_cnt[1])
-        hipLaunchKernelGGL((ksw_backtrack_kernel<2>), dim3((bin_cnt[1] + 63) / 64), dim3(64), 0, st, d_t + o, bin_cnt[1], d_z, d_cig, d_ncig);
-    o += bin_cnt[1];
-    launch_wave<MODE, 4>(cx, d_t + o, bin_cnt[2], d_seq, d_prm, d_out, d_z);
-    if (MODE == MODE_GLOBAL && bin_cnt[2])
-        hipLaunchKernelGGL((ksw_backtrack_kernel<4>), dim3((bin_cnt[2] + 63) / 64), dim3(64), 0, st, d_t + o, bin_cnt[2], d_z, d_cig, d_ncig);
-    o += bin_cnt[2];
-    if (bin_cnt[3])
-        hipLaunchKernelGGL((ksw_scalar_kernel<MODE>), dim3((bin_cnt[3] + 63) / 64), dim3(64), 0, st, d_t + o, bin_cnt[3], d_seq, d_prm, d_out,
-                           cx->d_scratch.as<int2>(), d_z, d_cig, d_ncig);
-    ALFA_HIP(hipGetLastError());
-    ALFA_HIP(hipEventRecord(cx->ev[2], st));
-    ALFA_HIP(hipMemcpyAsync(cx->h_out.p, d_out, out_bytes, hipMemcpyDeviceToHost, st));
-    if (MODE == MODE_GLOBAL)
-        ALFA_HIP(hipMemcpyAsync(cx->h_out2.p, d_cig, 4 * (size_t)cig_words + 4 * (size_t)n, hipMemcpyDeviceToHost, st));
-    ALFA_HIP(hipEventRecord(cx->ev[3], st));
-    ALFA_HIP(hipStreamSynchronize(st));
-    float ms = 0;
-    ALFA_HIP(hipEventElapsedTime(&ms, cx->ev[0], cx->ev[1])); alfa::g_last_timing.h2d_ms += ms;
-    ALFA_HIP(hipEventElapsedTime(&ms, cx->ev[1], cx->ev[2])); alfa::g_last_timing.kernel_ms += ms;
-    ALFA_HIP(hipEventElapsedTime(&ms, cx->ev[2], cx->ev[3])); alfa::g_last_timing.d2h_ms += ms;
-    alfa::g_last_timing.launches += 1;
-
-    // ---- scatter results back to the caller's order
-    if (MODE == MODE_EXTEND) {
-        const ExtOut* r = cx->h_out.as<ExtOut>();
-        alfa_extend_result* dst = (alfa_extend_result*)out_host;
-        for (int k = 0; k < n; ++k) memcpy(&dst[dense_of[k]], &r[k], sizeof(ExtOut));
-    } else {
-        const int32_t* r = cx->h_out.as<int32_t>();
-        int32_t* dst = (int32_t*)out_host;
-        for (int k = 0; k < n; ++k) dst[dense_of[k]] = r[k];
-    }
-    if (MODE == MODE_GLOBAL) {
-        const uint32_t* hc = cx->h_out2.as<uint32_t>();
-        const int32_t* hn = (const int32_t*)(hc + cig_words);
-        for (int k = 0; k < n; ++k) {
-            const int id = dense_of[k];
-            int nc = hn[k];
-            ncig_host[id] = nc;
-            if (nc > 0) {
-                const uint32_t* slot = hc + ht[k].cigoff;
-                (*cigs)[id].assign(slot + ht[k].cigcap - nc, slot + ht[k].cigcap);
-            }
-        }
-    }
     return ALFA_OK;
 }
 
@@ -676,41 +527,259 @@ int effective_w(int mode, const alfa_dp_params* p, const alfa_dp_task& x) {
     return w;
 }
 
+// cells of the static band envelope: sum_i (min(i+w+1,qlen) - max(i-w,0))^+   
+int64_t band_cells(int64_t qlen, int64_t tlen, int64_t w) {
+    int64_t c = 0;
+    // closed form would do; rows are few enough to take the three regimes directly
+    for (int64_t i = 0; i < tlen; ++i) {
+        const int64_t b0 = i > w ? i - w : 0, e0 = std::min<int64_t>(i + w + 1, qlen);
+        if (e0 > b0) c += e0 - b0; else if (b0 >= qlen) break;
+    }
+    return c;
+}
+
+template <int MODE, int C>
+void launch_wave(hipStream_t st, const DevTask* d_tasks, int n, const uint8_t* d_seq, const DevParams* d_prm, int32_t* d_out, uint8_t* d_z) {
+    if (n <= 0) return;
+    dim3 grid((n + WPB - 1) / WPB), block(64 * WPB);
+    hipLaunchKernelGGL((ksw_wave_kernel<MODE, C>), grid, block, 0, st, d_tasks, n, d_seq, d_prm, d_out, d_z);
+}
+
 template <int MODE>
-int run_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, void* out, std::vector<std::vector<uint32_t>>* cigs, int32_t* ncig) {
-    alfa::g_last_timing = alfa::Timing();
-    if (n < 0 || (n > 0 && (!t || !out))) return alfa::fail(ALFA_EINVAL, "null task/result array");
-    DevParams hp;
-    int rc = pack_params(p, &hp);
+void launch_all(alfa_dp_batch* b, hipStream_t st) {
+    const DevParams* d_prm = b->d_tasks.as<DevParams>();
+    const DevTask* d_t = (const DevTask*)(d_prm + 1);
+    const uint8_t* d_seq = b->d_seq.as<uint8_t>();
+    int32_t* d_out = b->d_out.as<int32_t>();
+    uint8_t* d_z = b->d_z.as<uint8_t>();
+    uint32_t* d_cig = b->d_cig.as<uint32_t>();
+    int32_t* d_ncig = MODE == MODE_GLOBAL ? (int32_t*)(d_cig + b->cig_words) : nullptr;
+    const int* bc = b->bin_cnt;
+    int o = 0;
+    launch_wave<MODE, 1>(st, d_t + o, bc[0], d_seq, d_prm, d_out, d_z);
+    if (MODE == MODE_GLOBAL && bc[0])
+        hipLaunchKernelGGL((ksw_backtrack_kernel<1>), dim3((bc[0] + 63) / 64), dim3(64), 0, st, d_t + o, bc[0], d_z, d_cig, d_ncig);
+    o += bc[0];
+    launch_wave<MODE, 2>(st, d_t + o, bc[1], d_seq, d_prm, d_out, d_z);
+    if (MODE == MODE_GLOBAL && bc[1])
+        hipLaunchKernelGGL((ksw_backtrack_kernel<2>), dim3((bc[1] + 63) / 64), dim3(64), 0, st, d_t + o, bc[1], d_z, d_cig, d_ncig);
+    o += bc[1];
+    launch_wave<MODE, 4>(st, d_t + o, bc[2], d_seq, d_prm, d_out, d_z);
+    if (MODE == MODE_GLOBAL && bc[2])
+        hipLaunchKernelGGL((ksw_backtrack_kernel<4>), dim3((bc[2] + 63) / 64), dim3(64), 0, st, d_t + o, bc[2], d_z, d_cig, d_ncig);
+    o += bc[2];
+    if (bc[3])
+        hipLaunchKernelGGL((ksw_scalar_kernel<MODE>), dim3((bc[3] + 63) / 64), dim3(64), 0, st, d_t + o, bc[3], d_seq, d_prm, d_out,
+                           b->d_eh.as<int2>(), d_z, d_cig, d_ncig);
+}
+
+// (re)fills `b` for tasks ids[] of t[]; buffers of `b` are reused when large enough
+int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, const alfa_dp_task* t, const int* ids, int n) {
+    int rc = pack_params(p, &b->hp);
     if (rc) return rc;
+    b->mode = mode; b->n = n; b->device = cx->device; b->launched = false; b->kernel_ms = 0;
+    b->cig_words = b->cells = b->zbytes = b->eh_items = 0;
+    for (int k = 0; k < 4; ++k) b->bin_cnt[k] = 0;
+    b->ht.resize((size_t)n);
+    b->dense_of.resize((size_t)n);
+    if (!b->ev0) { ALFA_HIP(hipEventCreate(&b->ev0)); ALFA_HIP(hipEventCreate(&b->ev1)); }
     if (n == 0) return ALFA_OK;
-    int dev = 0;
+    std::vector<int> w_eff((size_t)n), bins((size_t)n), perm((size_t)n);
+    size_t seq_bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        const alfa_dp_task& x = t[ids ? ids[i] : i];
+        if (x.qlen < 0 || x.tlen < 0 || x.w < 0) return alfa::fail(ALFA_EINVAL, "negative length or band in a DP task");
+        if ((x.qlen > 0 && !x.query) || (x.tlen > 0 && !x.target)) return alfa::fail(ALFA_EINVAL, "null sequence pointer in a DP task");
+        w_eff[i] = effective_w(mode, p, x);
+        int bin;
+        if (x.qlen == 0 || x.tlen == 0) bin = 3;
+        else { const int W = 2 * w_eff[i] + 1; bin = W <= 64 ? 0 : W <= 128 ? 1 : W <= 256 ? 2 : 3; }
+        bins[i] = bin;
+        b->bin_cnt[bin]++;
+        seq_bytes += (size_t)x.qlen + (size_t)x.tlen;
+    }
+    // order: by bin, longest targets first so that co-resident waves retire together
+    std::iota(perm.begin(), perm.end(), 0);
+    std::sort(perm.begin(), perm.end(), [&](int a, int c) {
+        if (bins[a] != bins[c]) return bins[a] < bins[c];
+        const int ta = t[ids ? ids[a] : a].tlen, tc = t[ids ? ids[c] : c].tlen;
+        if (ta != tc) return ta > tc;
+        return a < c;
+    });
+    b->seq_bytes = seq_bytes;
+    if ((rc = cx->h_in.reserve(seq_bytes + 64)) || (rc = cx->h_tasks.reserve(sizeof(DevTask) * (size_t)n + sizeof(DevParams))) ||
+        (rc = b->d_seq.reserve(seq_bytes + 64)) || (rc = b->d_tasks.reserve(sizeof(DevTask) * (size_t)n + sizeof(DevParams))))
+        return rc;
+    uint8_t* hs = cx->h_in.as<uint8_t>();
+    DevParams* hprm = cx->h_tasks.as<DevParams>();
+    DevTask* ht = (DevTask*)(hprm + 1);
+    *hprm = b->hp;
+    size_t so = 0;
+    const int Cs[4] = {1, 2, 4, 0};
+    const int m = b->hp.m;
+    for (int k = 0; k < n; ++k) {
+        const int li = perm[k];
+        const int id = ids ? ids[li] : li;
+        const alfa_dp_task& x = t[id];
+        DevTask& d = ht[k];
+        memset(&d, 0, sizeof(d));
+        d.qoff = (int64_t)so;
+        for (int j = 0; j < x.qlen; ++j) { const uint8_t c = x.query[j]; if (c >= m) return alfa::fail(ALFA_EINVAL, "query residue code >= m"); hs[so + j] = c; }
+        so += (size_t)x.qlen;
+        d.toff = (int64_t)so;
+        for (int j = 0; j < x.tlen; ++j) { const uint8_t c = x.target[j]; if (c >= m) return alfa::fail(ALFA_EINVAL, "target residue code >= m"); hs[so + j] = c; }
+        so += (size_t)x.tlen;
+        d.qlen = x.qlen; d.tlen = x.tlen; d.w = w_eff[li]; d.h0 = x.h0; d.orig = k;
+        b->dense_of[k] = li;
+        if (bins[li] == 3) { d.ehoff = b->eh_items; b->eh_items += (int64_t)x.qlen + 2; }
+        if (mode == MODE_GLOBAL) {
+            d.zoff = b->zbytes;
+            if (bins[li] == 3) b->zbytes += std::min<int64_t>(x.qlen, 2 * (int64_t)d.w + 1) * x.tlen;
+            else b->zbytes += (int64_t)x.tlen * 64 * Cs[bins[li]];
+            b->zbytes = (b->zbytes + 15) & ~(int64_t)15;
+            d.cigoff = b->cig_words;
+            d.cigcap = x.qlen + x.tlen + 2;
+            b->cig_words += d.cigcap;
+        }
+        b->cells += band_cells(x.qlen, x.tlen, d.w);
+        b->ht[k] = d;
+    }
+    b->out_bytes = (mode == MODE_EXTEND ? sizeof(ExtOut) : sizeof(int32_t)) * (size_t)n;
+    if ((rc = b->d_out.reserve(b->out_bytes)) || (rc = b->h_out.reserve(b->out_bytes))) return rc;
+    if (b->eh_items && (rc = b->d_eh.reserve(sizeof(int2) * (size_t)b->eh_items))) return rc;
+    if (mode == MODE_GLOBAL) {
+        const size_t cb = 4 * (size_t)b->cig_words + 4 * (size_t)n;
+        if ((rc = b->d_z.reserve((size_t)b->zbytes + 64)) || (rc = b->d_cig.reserve(cb)) || (rc = b->h_cig.reserve(cb))) return rc;
+    }
+    hipStream_t st = cx->stream;
+    ALFA_HIP(hipMemcpyAsync(b->d_seq.p, hs, seq_bytes, hipMemcpyHostToDevice, st));
+    ALFA_HIP(hipMemcpyAsync(b->d_tasks.p, hprm, sizeof(DevParams) + sizeof(DevTask) * (size_t)n, hipMemcpyHostToDevice, st));
+    ALFA_HIP(hipStreamSynchronize(st));   // staging buffers of the context are free again
+    return ALFA_OK;
+}
+
+int launch_batch(alfa_dp_batch* b, Ctx* cx) {
+    if (b->n == 0) { b->launched = true; return ALFA_OK; }
+    hipStream_t st = cx->stream;
+    ALFA_HIP(hipEventRecord(b->ev0, st));
+    if (b->mode == MODE_EXTEND) launch_all<MODE_EXTEND>(b, st);
+    else if (b->mode == MODE_NW) launch_all<MODE_NW>(b, st);
+    else launch_all<MODE_GLOBAL>(b, st);
+    ALFA_HIP(hipGetLastError());
+    ALFA_HIP(hipEventRecord(b->ev1, st));
+    b->launched = true;
+    return ALFA_OK;
+}
+
+// per-task CIGAR vectors are appended to `cigs` (indexed by the position in ids[]) when GLOBAL
+int fetch_batch(alfa_dp_batch* b, Ctx* cx, void* out_host, const int* ids, std::vector<std::vector<uint32_t>>* cigs, int32_t* ncig_host) {
+    if (!b->launched) return alfa::fail(ALFA_EINVAL, "fetch before launch");
+    const int n = b->n;
+    if (n == 0) return ALFA_OK;
+    hipStream_t st = cx->stream;
+    ALFA_HIP(hipMemcpyAsync(b->h_out.p, b->d_out.p, b->out_bytes, hipMemcpyDeviceToHost, st));
+    if (b->mode == MODE_GLOBAL)
+        ALFA_HIP(hipMemcpyAsync(b->h_cig.p, b->d_cig.p, 4 * (size_t)b->cig_words + 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    ALFA_HIP(hipStreamSynchronize(st));
+    float ms = 0;
+    ALFA_HIP(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    b->kernel_ms = ms;
+    auto dst_index = [&](int k) { const int li = b->dense_of[k]; return ids ? ids[li] : li; };
+    if (b->mode == MODE_EXTEND) {
+        const ExtOut* r = b->h_out.as<ExtOut>();
+        alfa_extend_result* dst = (alfa_extend_result*)out_host;
+        for (int k = 0; k < n; ++k) memcpy(&dst[dst_index(k)], &r[k], sizeof(ExtOut));
+    } else {
+        const int32_t* r = b->h_out.as<int32_t>();
+        int32_t* dst = (int32_t*)out_host;
+        for (int k = 0; k < n; ++k) dst[dst_index(k)] = r[k];
+    }
+    if (b->mode == MODE_GLOBAL) {
+        const uint32_t* hc = b->h_cig.as<uint32_t>();
+        const int32_t* hn = (const int32_t*)(hc + b->cig_words);
+        for (int k = 0; k < n; ++k) {
+            const int id = dst_index(k);
+            const int nc = hn[k];
+            ncig_host[id] = nc;
+            (*cigs)[id].clear();
+            if (nc > 0) {
+                const uint32_t* slot = hc + b->ht[k].cigoff;
+                (*cigs)[id].assign(slot + b->ht[k].cigcap - nc, slot + b->ht[k].cigcap);
+            }
+        }
+    }
+    return ALFA_OK;
+}
+
+int current_ctx(Ctx** out, int device = -1) {
     if (alfa::device_count() <= 0) return alfa::fail(ALFA_ENODEV, "no HIP device is usable; libalfa_hot has no CPU fallback");
-    (void)hipGetDevice(&dev);
+    int dev = device;
+    if (dev < 0) (void)hipGetDevice(&dev);
     Ctx* cx = alfa::thread_ctx(dev);
     if (!cx) return ALFA_ENODEV;
-    std::vector<int> w_eff(n);
-    for (int i = 0; i < n; ++i) {
-        if (t[i].qlen < 0 || t[i].tlen < 0 || t[i].w < 0) return alfa::fail(ALFA_EINVAL, "negative length or band in a DP task");
-        if ((t[i].qlen > 0 && !t[i].query) || (t[i].tlen > 0 && !t[i].target)) return alfa::fail(ALFA_EINVAL, "null sequence pointer in a DP task");
-        w_eff[i] = effective_w(MODE, p, t[i]);
-    }
-    // chunk so that one launch needs at most ~6 GiB of direction bytes / staging
-    const int64_t LIMIT = (int64_t)6 << 30;
-    std::vector<int> ids;
-    int64_t need = 0, cells = 0;
-    for (int i = 0; i < n; ++i) {
-        int64_t z = MODE == MODE_GLOBAL ? (int64_t)t[i].tlen * 256 : 0;
-        z += t[i].qlen + t[i].tlen;
-        if (!ids.empty() && need + z > LIMIT) {
-            if ((rc = run_range<MODE>(cx, hp, t, w_eff.data(), ids, out, cigs, ncig, &cells))) return rc;
+    *out = cx;
+    return ALFA_OK;
+}
+
+void release_batch(alfa_dp_batch* b) {
+    b->d_seq.release(); b->d_tasks.release(); b->d_out.release(); b->d_z.release(); b->d_cig.release(); b->d_eh.release();
+    b->h_out.release(); b->h_cig.release();
+    if (b->ev0) { (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); b->ev0 = b->ev1 = nullptr; }
+}
+
+int pack_cigars(const std::vector<std::vector<uint32_t>>& cigs, int n, uint32_t** cigar, int64_t* cig_off) {
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) { cig_off[i] = total; total += (int64_t)cigs[i].size(); }
+    cig_off[n] = total;
+    uint32_t* outc = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(total + 1));
+    if (!outc) return alfa::fail(ALFA_ENOMEM, "out of host memory for CIGAR output");
+    for (int i = 0; i < n; ++i)
+        if (!cigs[i].empty()) memcpy(outc + cig_off[i], cigs[i].data(), sizeof(uint32_t) * cigs[i].size());
+    *cigar = outc;
+    return ALFA_OK;
+}
+
+// synchronous call: chunks of bounded device footprint through one per-thread reusable batch object
+int run_sync(int mode, const alfa_dp_params* p, const alfa_dp_task* t, int n, void* out, uint32_t** cigar, int32_t* ncig, int64_t* cig_off) {
+    alfa::g_last_timing = alfa::Timing();
+    if (n < 0 || (n > 0 && (!t || !out))) return alfa::fail(ALFA_EINVAL, "null task/result array");
+    if (mode == MODE_GLOBAL && n >= 0 && (!cigar || !ncig || !cig_off)) return alfa::fail(ALFA_EINVAL, "null CIGAR output argument");
+    DevParams tmp;
+    int rc = pack_params(p, &tmp);
+    if (rc) return rc;
+    std::vector<std::vector<uint32_t>> cigs;
+    if (mode == MODE_GLOBAL) cigs.resize((size_t)n);
+    if (n > 0) {
+        Ctx* cx;
+        if ((rc = current_ctx(&cx))) return rc;
+        thread_local alfa_dp_batch* reuse[3] = {nullptr, nullptr, nullptr};
+        if (!reuse[mode]) reuse[mode] = new alfa_dp_batch();
+        alfa_dp_batch* b = reuse[mode];
+        const int64_t LIMIT = (int64_t)6 << 30;
+        std::vector<int> ids;
+        int64_t need = 0;
+        auto flush = [&]() -> int {
+            if (ids.empty()) return ALFA_OK;
+            int r;
+            if ((r = fill_batch(b, cx, mode, p, t, ids.data(), (int)ids.size()))) return r;
+            if ((r = launch_batch(b, cx))) return r;
+            if ((r = fetch_batch(b, cx, out, ids.data(), mode == MODE_GLOBAL ? &cigs : nullptr, ncig))) return r;
+            alfa::g_last_timing.kernel_ms += b->kernel_ms;
+            alfa::g_last_timing.work_units += b->cells;
+            alfa::g_last_timing.launches += 1;
             ids.clear(); need = 0;
+            return ALFA_OK;
+        };
+        for (int i = 0; i < n; ++i) {
+            int64_t z = mode == MODE_GLOBAL ? (int64_t)t[i].tlen * 256 + 4 * ((int64_t)t[i].qlen + t[i].tlen) : 0;
+            z += (int64_t)t[i].qlen + t[i].tlen;
+            if (!ids.empty() && need + z > LIMIT) { if ((rc = flush())) return rc; }
+            ids.push_back(i);
+            need += z;
         }
-        ids.push_back(i);
-        need += z;
+        if ((rc = flush())) return rc;
     }
-    if ((rc = run_range<MODE>(cx, hp, t, w_eff.data(), ids, out, cigs, ncig, &cells))) return rc;
-    alfa::g_last_timing.work_units = cells;
+    if (mode == MODE_GLOBAL) return pack_cigars(cigs, n, cigar, cig_off);
     return ALFA_OK;
 }
 
@@ -719,27 +788,82 @@ int run_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, void* out, 
 extern "C" {
 
 int alfa_ksw_extend_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, alfa_extend_result* r) {
-    return run_batch<MODE_EXTEND>(p, t, n, r, nullptr, nullptr);
+    return run_sync(MODE_EXTEND, p, t, n, r, nullptr, nullptr, nullptr);
 }
-
 int alfa_ksw_nw_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, int32_t* score) {
-    return run_batch<MODE_NW>(p, t, n, score, nullptr, nullptr);
+    return run_sync(MODE_NW, p, t, n, score, nullptr, nullptr, nullptr);
 }
-
 int alfa_ksw_global_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, int32_t* score, uint32_t** cigar, int32_t* n_cigar,
                           int64_t* cig_off) {
-    if (n > 0 && (!cigar || !n_cigar || !cig_off)) return alfa::fail(ALFA_EINVAL, "null CIGAR output argument");
-    std::vector<std::vector<uint32_t>> cigs((size_t)std::max(n, 0));
-    int rc = run_batch<MODE_GLOBAL>(p, t, n, score, &cigs, n_cigar);
+    return run_sync(MODE_GLOBAL, p, t, n, score, cigar, n_cigar, cig_off);
+}
+
+int alfa_dp_batch_create(int mode, const alfa_dp_params* p, const alfa_dp_task* t, int n, int device, alfa_dp_batch** out) {
+    if (!out || mode < 0 || mode > 2 || n < 0 || (n > 0 && !t)) return alfa::fail(ALFA_EINVAL, "bad argument");
+    Ctx* cx;
+    int rc = current_ctx(&cx, device);
     if (rc) return rc;
-    int64_t total = 0;
-    for (int i = 0; i < n; ++i) { cig_off[i] = total; total += (int64_t)cigs[i].size(); }
-    if (cig_off) cig_off[n > 0 ? n : 0] = total;
-    uint32_t* outc = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(total + 1));
-    if (!outc) return alfa::fail(ALFA_ENOMEM, "out of host memory for CIGAR output");
-    for (int i = 0; i < n; ++i)
-        if (!cigs[i].empty()) memcpy(outc + cig_off[i], cigs[i].data(), sizeof(uint32_t) * cigs[i].size());
-    *cigar = outc;
+    alfa_dp_batch* b = new alfa_dp_batch();
+    if ((rc = fill_batch(b, cx, mode, p, t, nullptr, n))) { release_batch(b); delete b; return rc; }
+    *out = b;
+    return ALFA_OK;
+}
+int alfa_dp_batch_launch(alfa_dp_batch* b) {
+    if (!b) return alfa::fail(ALFA_EINVAL, "null batch");
+    Ctx* cx;
+    int rc = current_ctx(&cx, b->device);
+    if (rc) return rc;
+    return launch_batch(b, cx);
+}
+int alfa_dp_batch_fetch(alfa_dp_batch* b, void* out, uint32_t** cigar, int32_t* n_cigar, int64_t* cig_off) {
+    if (!b || (b->n > 0 && !out)) return alfa::fail(ALFA_EINVAL, "null argument");
+    if (b->mode == MODE_GLOBAL && (!cigar || !n_cigar || !cig_off)) return alfa::fail(ALFA_EINVAL, "null CIGAR output argument");
+    Ctx* cx;
+    int rc = current_ctx(&cx, b->device);
+    if (rc) return rc;
+    std::vector<std::vector<uint32_t>> cigs;
+    if (b->mode == MODE_GLOBAL) cigs.resize((size_t)b->n);
+    if ((rc = fetch_batch(b, cx, out, nullptr, b->mode == MODE_GLOBAL ? &cigs : nullptr, n_cigar))) return rc;
+    if (b->mode == MODE_GLOBAL) return pack_cigars(cigs, b->n, cigar, cig_off);
+    return ALFA_OK;
+}
+int64_t alfa_dp_batch_cells(const alfa_dp_batch* b) { return b ? b->cells : 0; }
+double alfa_dp_batch_kernel_ms(const alfa_dp_batch* b) {
+    if (!b || !b->launched || b->n == 0) return 0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) { (void)hipGetLastError(); return b->kernel_ms; }
+    return ms;
+}
+void alfa_dp_batch_free(alfa_dp_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    release_batch(b);
+    delete b;
+}
+
+int alfa_sync(int device) {
+    Ctx* cx;
+    int rc = current_ctx(&cx, device);
+    if (rc) return rc;
+    ALFA_HIP(hipStreamSynchronize(cx->stream));
+    return ALFA_OK;
+}
+int alfa_timer_start(int device) {
+    Ctx* cx;
+    int rc = current_ctx(&cx, device);
+    if (rc) return rc;
+    ALFA_HIP(hipEventRecord(cx->ev[0], cx->stream));
+    return ALFA_OK;
+}
+int alfa_timer_stop(int device, double* ms) {
+    Ctx* cx;
+    int rc = current_ctx(&cx, device);
+    if (rc) return rc;
+    ALFA_HIP(hipEventRecord(cx->ev[1], cx->stream));
+    ALFA_HIP(hipEventSynchronize(cx->ev[1]));
+    float f = 0;
+    ALFA_HIP(hipEventElapsedTime(&f, cx->ev[0], cx->ev[1]));
+    if (ms) *ms = f;
     return ALFA_OK;
 }
 

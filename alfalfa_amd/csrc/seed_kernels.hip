@@ -271,10 +271,13 @@ struct PatG {   // read bytes straight from global memory (kernel B touches only
 
 // ---------------------------------------------------------------- kernel B: emit
 __global__ void smam_emit_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
-                                 const int64_t* __restrict__ read_base, const WorkRec* __restrict__ work, int nwork,
-                                 alfa_match* __restrict__ out) {
+                                 const int64_t* __restrict__ read_base, int nq, const WorkRec* __restrict__ work,
+                                 const int* __restrict__ work_count, int work_cap, alfa_match* __restrict__ out, int64_t out_cap) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nwork) return;
+    const int nwork = *work_count;
+    // an overflowing work list or match array is detected by the host at fetch time, which re-launches with
+    // larger buffers; nothing is written here in that case
+    if (nwork > work_cap || read_base[nq] > out_cap || g >= nwork) return;
     const WorkRec w = work[g];
     const SeedQ Q = qs[w.read];
     PatG P; P.p = reads + Q.poff; P.len = Q.plen;
@@ -347,20 +350,39 @@ void alfa_index_free(alfa_index* ix) {
 
 int alfa_index_device(const alfa_index* ix) { return ix ? ix->device : -1; }
 
-int alfa_seed_batch(alfa_index* ix, int mem_type, const alfa_seed_query* q, int nq, alfa_match** matches, int64_t* offsets) {
-    alfa::g_last_timing = alfa::Timing();
-    if (!ix || !matches || !offsets || nq < 0 || (nq > 0 && !q)) return alfa::fail(ALFA_EINVAL, "null argument");
+}  // extern "C"
+
+struct alfa_seed_plan {
+    alfa_index* ix = nullptr;
+    int nq = 0, max_plen = 0;
+    int64_t total_pref = 0;
+    size_t read_bytes = 0;
+    int work_cap = 0;
+    int64_t out_cap = 0;
+    alfa::DevBuf d_reads, d_q, d_tot, d_base, d_work, d_out, d_tmp;
+    size_t tmp_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool launched = false;
+};
+
+namespace {
+
+DIdx make_didx(const alfa_index* ix) {
+    DIdx X;
+    X.S = ix->S.as<uint8_t>(); X.SA = ix->SA.as<uint32_t>(); X.LCP = ix->LCP.as<uint8_t>();
+    X.Midx = ix->Midx.as<int64_t>(); X.Mval = ix->Mval.as<int32_t>(); X.CHILD = ix->CHILD.as<int32_t>();
+    X.KMR = ix->KMR.as<uint2>();
+    X.N = ix->N; X.n = (int32_t)ix->n; X.nM = (int32_t)ix->nM; X.K = (int32_t)ix->K; X.has_kmer = ix->has_kmer;
+    return X;
+}
+
+int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, const alfa_seed_query* q, int nq) {
     if (mem_type != ALFA_SEED_SMAM)
         return alfa::fail(ALFA_ENOTSUP, "only ALFA_SEED_SMAM (the reference's default seed type) has a HIP kernel so far");
     if (!ix->has_child) return alfa::fail(ALFA_ENOTSUP, "the HIP seed kernels need an index with a child table (--no-child unsupported)");
     if (ix->has_suflink) return alfa::fail(ALFA_ENOTSUP, "suffix-link (--suflink) indexes are not supported by the HIP seed kernels");
-    alfa::Ctx* cx = alfa::thread_ctx(ix->device);
-    if (!cx) return ALFA_ENODEV;
-    *matches = nullptr;
-    offsets[0] = 0;
-    if (nq == 0) { *matches = (alfa_match*)malloc(sizeof(alfa_match)); return ALFA_OK; }
-
-    // ---- pack reads + query descriptors
+    pl->ix = ix; pl->nq = nq; pl->launched = false;
+    if (!pl->ev0) { ALFA_HIP(hipEventCreate(&pl->ev0)); ALFA_HIP(hipEventCreate(&pl->ev1)); }
     size_t bytes = 0;
     int max_plen = 0;
     for (int i = 0; i < nq; ++i) {
@@ -369,10 +391,12 @@ int alfa_seed_batch(alfa_index* ix, int mem_type, const alfa_seed_query* q, int 
         bytes += (size_t)q[i].plen;
         max_plen = std::max(max_plen, q[i].plen);
     }
+    pl->read_bytes = bytes; pl->max_plen = max_plen;
+    if (nq == 0) return ALFA_OK;
     int rc;
     if ((rc = cx->h_in.reserve(bytes + 64)) || (rc = cx->h_tasks.reserve(sizeof(SeedQ) * (size_t)nq)) ||
-        (rc = cx->d_in.reserve(bytes + 64)) || (rc = cx->d_tasks.reserve(sizeof(SeedQ) * (size_t)nq)) ||
-        (rc = cx->d_cnt.reserve(8 * ((size_t)nq + 1) + 64)) || (rc = cx->d_off.reserve(8 * ((size_t)nq + 1) + 64)))
+        (rc = pl->d_reads.reserve(bytes + 64)) || (rc = pl->d_q.reserve(sizeof(SeedQ) * (size_t)nq)) ||
+        (rc = pl->d_tot.reserve(8 * ((size_t)nq + 1) + 64)) || (rc = pl->d_base.reserve(8 * ((size_t)nq + 1) + 64)))
         return rc;
     uint8_t* hp = cx->h_in.as<uint8_t>();
     SeedQ* hq = cx->h_tasks.as<SeedQ>();
@@ -390,80 +414,143 @@ int alfa_seed_batch(alfa_index* ix, int mem_type, const alfa_seed_query* q, int 
         if (q[i].plen) memcpy(hp + po, q[i].P, (size_t)q[i].plen);
         po += (size_t)q[i].plen;
     }
-    DIdx X;
-    X.S = ix->S.as<uint8_t>(); X.SA = ix->SA.as<uint32_t>(); X.LCP = ix->LCP.as<uint8_t>();
-    X.Midx = ix->Midx.as<int64_t>(); X.Mval = ix->Mval.as<int32_t>(); X.CHILD = ix->CHILD.as<int32_t>();
-    X.KMR = ix->KMR.as<uint2>();
-    X.N = ix->N; X.n = (int32_t)ix->n; X.nM = (int32_t)ix->nM; X.K = (int32_t)ix->K; X.has_kmer = ix->has_kmer;
+    pl->total_pref = total_pref;
+    pl->work_cap = (int)std::min<int64_t>(std::max<int64_t>(4096, 4 * (int64_t)nq), std::max<int64_t>(total_pref, 1));
+    pl->out_cap = std::max<int64_t>(4096, 16 * (int64_t)nq);
+    pl->tmp_bytes = 0;
+    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, pl->tmp_bytes, pl->d_tot.as<int64_t>(), pl->d_base.as<int64_t>(), nq + 1, cx->stream));
+    if ((rc = pl->d_work.reserve(sizeof(WorkRec) * (size_t)pl->work_cap + 64)) ||
+        (rc = pl->d_out.reserve(sizeof(alfa_match) * (size_t)pl->out_cap)) || (rc = pl->d_tmp.reserve(pl->tmp_bytes + 64)))
+        return rc;
+    ALFA_HIP(hipMemcpyAsync(pl->d_reads.p, hp, bytes, hipMemcpyHostToDevice, cx->stream));
+    ALFA_HIP(hipMemcpyAsync(pl->d_q.p, hq, sizeof(SeedQ) * (size_t)nq, hipMemcpyHostToDevice, cx->stream));
+    ALFA_HIP(hipStreamSynchronize(cx->stream));
+    return ALFA_OK;
+}
 
+int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
+    pl->launched = true;
+    if (pl->nq == 0) return ALFA_OK;
     hipStream_t st = cx->stream;
-    const int lds_p = max_plen <= 48 * 1024;
-    const size_t lds_bytes = lds_p ? (size_t)max_plen + 16 : 0;
-    ALFA_HIP(hipEventRecord(cx->ev[0], st));
-    ALFA_HIP(hipMemcpyAsync(cx->d_in.p, hp, bytes, hipMemcpyHostToDevice, st));
-    ALFA_HIP(hipMemcpyAsync(cx->d_tasks.p, hq, sizeof(SeedQ) * (size_t)nq, hipMemcpyHostToDevice, st));
-    int64_t* d_tot = cx->d_cnt.as<int64_t>();
-    int64_t* d_base = cx->d_off.as<int64_t>();
-    // work list: grows (and the count kernel is re-run) only if the first guess overflows
-    int work_cap = (int)std::min<int64_t>(std::max<int64_t>(4096, 4 * (int64_t)nq), std::max<int64_t>(total_pref, 1));
-    int nwork = 0;
-    float ms_kernel = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if ((rc = cx->d_ivl.reserve(sizeof(WorkRec) * (size_t)work_cap + 64))) return rc;
-        int* d_wc = (int*)((char*)cx->d_ivl.p + sizeof(WorkRec) * (size_t)work_cap);
-        ALFA_HIP(hipMemsetAsync(d_wc, 0, 4, st));
-        ALFA_HIP(hipMemsetAsync(d_tot + nq, 0, 8, st));
-        ALFA_HIP(hipEventRecord(cx->ev[1], st));
-        hipLaunchKernelGGL(smam_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, cx->d_tasks.as<SeedQ>(), cx->d_in.as<uint8_t>(),
-                           d_tot, cx->d_ivl.as<WorkRec>(), d_wc, work_cap, lds_p);
-        ALFA_HIP(hipGetLastError());
-        ALFA_HIP(hipEventRecord(cx->ev[2], st));
+    const DIdx X = make_didx(pl->ix);
+    const int nq = pl->nq;
+    const int lds_p = pl->max_plen <= 48 * 1024;
+    const size_t lds_bytes = lds_p ? (size_t)pl->max_plen + 16 : 0;
+    int* d_wc = (int*)((char*)pl->d_work.p + sizeof(WorkRec) * (size_t)pl->work_cap);
+    int64_t* d_tot = pl->d_tot.as<int64_t>();
+    int64_t* d_base = pl->d_base.as<int64_t>();
+    ALFA_HIP(hipMemsetAsync(d_wc, 0, 4, st));
+    ALFA_HIP(hipMemsetAsync(d_tot + nq, 0, 8, st));
+    ALFA_HIP(hipEventRecord(pl->ev0, st));
+    hipLaunchKernelGGL(smam_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, pl->d_q.as<SeedQ>(), pl->d_reads.as<uint8_t>(), d_tot,
+                       pl->d_work.as<WorkRec>(), d_wc, pl->work_cap, lds_p);
+    ALFA_HIP(hipGetLastError());
+    ALFA_HIP(hipEventRecord(pl->ev1, st));
+    size_t tb = pl->tmp_bytes;
+    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_tmp.p, tb, d_tot, d_base, nq + 1, st));
+    hipLaunchKernelGGL(smam_emit_kernel, dim3((pl->work_cap + 127) / 128), dim3(128), 0, st, X, pl->d_q.as<SeedQ>(), pl->d_reads.as<uint8_t>(),
+                       d_base, nq, pl->d_work.as<WorkRec>(), d_wc, pl->work_cap, pl->d_out.as<alfa_match>(), pl->out_cap);
+    ALFA_HIP(hipGetLastError());
+    return ALFA_OK;
+}
+
+int plan_fetch(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_match** matches, int64_t* offsets) {
+    if (!pl->launched) return alfa::fail(ALFA_EINVAL, "fetch before launch");
+    const int nq = pl->nq;
+    offsets[0] = 0;
+    if (nq == 0) { *matches = (alfa_match*)malloc(sizeof(alfa_match)); return ALFA_OK; }
+    hipStream_t st = cx->stream;
+    int rc;
+    for (int attempt = 0;; ++attempt) {
+        int nwork = 0;
+        int* d_wc = (int*)((char*)pl->d_work.p + sizeof(WorkRec) * (size_t)pl->work_cap);
         ALFA_HIP(hipMemcpyAsync(&nwork, d_wc, 4, hipMemcpyDeviceToHost, st));
+        ALFA_HIP(hipMemcpyAsync(offsets, pl->d_base.p, 8 * ((size_t)nq + 1), hipMemcpyDeviceToHost, st));
         ALFA_HIP(hipStreamSynchronize(st));
-        float ms = 0;
-        ALFA_HIP(hipEventElapsedTime(&ms, cx->ev[1], cx->ev[2]));
-        ms_kernel += ms;
-        alfa::g_last_timing.launches += 1;
-        if (nwork <= work_cap) break;
-        work_cap = nwork;
+        const int64_t total = offsets[nq];
+        if (nwork <= pl->work_cap && total <= pl->out_cap) break;
+        if (attempt >= 2) return alfa::fail(ALFA_EHIP, "seed work list kept overflowing");
+        // grow to the exact need reported by the device and run again
+        if (nwork > pl->work_cap) {
+            pl->work_cap = nwork;
+            if ((rc = pl->d_work.reserve(sizeof(WorkRec) * (size_t)pl->work_cap + 64))) return rc;
+        }
+        if (total > pl->out_cap) {
+            pl->out_cap = total;
+            if ((rc = pl->d_out.reserve(sizeof(alfa_match) * (size_t)pl->out_cap))) return rc;
+        }
+        if ((rc = plan_launch(pl, cx))) return rc;
     }
-    {
-        float ms = 0;
-        ALFA_HIP(hipEventElapsedTime(&ms, cx->ev[0], cx->ev[1]));
-        alfa::g_last_timing.h2d_ms = ms;
-    }
-    // ---- exclusive scan of per-read totals (nq+1 items so that base[nq] = grand total)
-    size_t tmp_bytes = 0;
-    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_tot, d_base, nq + 1, st));
-    if ((rc = cx->d_scratch.reserve(tmp_bytes + 64))) return rc;
-    ALFA_HIP(hipEventRecord(cx->ev[1], st));
-    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(cx->d_scratch.p, tmp_bytes, d_tot, d_base, nq + 1, st));
-    ALFA_HIP(hipMemcpyAsync(offsets, d_base, 8 * ((size_t)nq + 1), hipMemcpyDeviceToHost, st));
-    ALFA_HIP(hipStreamSynchronize(st));
     const int64_t total = offsets[nq];
     alfa_match* hm = (alfa_match*)malloc(sizeof(alfa_match) * (size_t)(total + 1));
     if (!hm) return alfa::fail(ALFA_ENOMEM, "out of host memory for the match array");
     if (total > 0) {
-        if ((rc = cx->d_out.reserve(sizeof(alfa_match) * (size_t)total))) { free(hm); return rc; }
-        hipLaunchKernelGGL(smam_emit_kernel, dim3((nwork + 127) / 128), dim3(128), 0, st, X, cx->d_tasks.as<SeedQ>(), cx->d_in.as<uint8_t>(),
-                           d_base, cx->d_ivl.as<WorkRec>(), nwork, cx->d_out.as<alfa_match>());
-        hipError_t e = hipGetLastError();
+        hipError_t e = hipMemcpyAsync(hm, pl->d_out.p, sizeof(alfa_match) * (size_t)total, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { free(hm); return alfa::fail(ALFA_EHIP, hipGetErrorString(e)); }
     }
-    ALFA_HIP(hipEventRecord(cx->ev[2], st));
-    if (total > 0) ALFA_HIP(hipMemcpyAsync(hm, cx->d_out.p, sizeof(alfa_match) * (size_t)total, hipMemcpyDeviceToHost, st));
-    ALFA_HIP(hipEventRecord(cx->ev[3], st));
-    ALFA_HIP(hipStreamSynchronize(st));
-    {
-        float ms = 0;
-        ALFA_HIP(hipEventElapsedTime(&ms, cx->ev[1], cx->ev[2]));
-        ms_kernel += ms;
-        ALFA_HIP(hipEventElapsedTime(&ms, cx->ev[2], cx->ev[3]));
-        alfa::g_last_timing.d2h_ms = ms;
-    }
-    alfa::g_last_timing.kernel_ms = ms_kernel;
-    alfa::g_last_timing.work_units = total_pref;
     *matches = hm;
+    return ALFA_OK;
+}
+
+void plan_release(alfa_seed_plan* pl) {
+    pl->d_reads.release(); pl->d_q.release(); pl->d_tot.release(); pl->d_base.release(); pl->d_work.release(); pl->d_out.release();
+    pl->d_tmp.release();
+    if (pl->ev0) { (void)hipEventDestroy(pl->ev0); (void)hipEventDestroy(pl->ev1); pl->ev0 = pl->ev1 = nullptr; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int alfa_seed_plan_create(alfa_index* ix, int mem_type, const alfa_seed_query* q, int nq, alfa_seed_plan** out) {
+    if (!ix || !out || nq < 0 || (nq > 0 && !q)) return alfa::fail(ALFA_EINVAL, "null argument");
+    alfa::Ctx* cx = alfa::thread_ctx(ix->device);
+    if (!cx) return ALFA_ENODEV;
+    alfa_seed_plan* pl = new alfa_seed_plan();
+    int rc = plan_fill(pl, cx, ix, mem_type, q, nq);
+    if (rc) { plan_release(pl); delete pl; return rc; }
+    *out = pl;
+    return ALFA_OK;
+}
+int alfa_seed_plan_launch(alfa_seed_plan* pl) {
+    if (!pl) return alfa::fail(ALFA_EINVAL, "null plan");
+    alfa::Ctx* cx = alfa::thread_ctx(pl->ix->device);
+    if (!cx) return ALFA_ENODEV;
+    return plan_launch(pl, cx);
+}
+int alfa_seed_plan_fetch(alfa_seed_plan* pl, alfa_match** matches, int64_t* offsets) {
+    if (!pl || !matches || !offsets) return alfa::fail(ALFA_EINVAL, "null argument");
+    alfa::Ctx* cx = alfa::thread_ctx(pl->ix->device);
+    if (!cx) return ALFA_ENODEV;
+    return plan_fetch(pl, cx, matches, offsets);
+}
+int64_t alfa_seed_plan_queries(const alfa_seed_plan* pl) { return pl ? pl->total_pref : 0; }
+double alfa_seed_plan_kernel_ms(const alfa_seed_plan* pl) {
+    if (!pl || !pl->launched || pl->nq == 0) return 0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, pl->ev0, pl->ev1) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return ms;
+}
+void alfa_seed_plan_free(alfa_seed_plan* pl) {
+    if (!pl) return;
+    (void)hipSetDevice(pl->ix->device);
+    plan_release(pl);
+    delete pl;
+}
+
+int alfa_seed_batch(alfa_index* ix, int mem_type, const alfa_seed_query* q, int nq, alfa_match** matches, int64_t* offsets) {
+    alfa::g_last_timing = alfa::Timing();
+    if (!ix || !matches || !offsets || nq < 0 || (nq > 0 && !q)) return alfa::fail(ALFA_EINVAL, "null argument");
+    alfa::Ctx* cx = alfa::thread_ctx(ix->device);
+    if (!cx) return ALFA_ENODEV;
+    thread_local alfa_seed_plan* reuse = nullptr;   // buffers are recycled from call to call
+    if (!reuse) reuse = new alfa_seed_plan();
+    int rc;
+    if ((rc = plan_fill(reuse, cx, ix, mem_type, q, nq)) || (rc = plan_launch(reuse, cx)) || (rc = plan_fetch(reuse, cx, matches, offsets))) return rc;
+    alfa::g_last_timing.kernel_ms = alfa_seed_plan_kernel_ms(reuse);
+    alfa::g_last_timing.work_units = reuse->total_pref;
+    alfa::g_last_timing.launches = 1;
     return ALFA_OK;
 }
 

@@ -299,3 +299,110 @@ def last_timing():
     t = Timing()
     check(lib().alfa_last_timing(C.byref(t)))
     return t
+
+
+# ------------------------------------------------------------------ resident batches (create / launch / fetch)
+DP_NW, DP_GLOBAL, DP_EXTEND = 0, 1, 2
+
+
+class DpBatch:
+    def __init__(self, mode, params, tasks, device=0):
+        self.mode, self.n = mode, len(tasks)
+        h = C.c_void_p()
+        check(lib().alfa_dp_batch_create(int(mode), C.byref(params), tasks, self.n, int(device), C.byref(h)))
+        self._h = h
+        L = lib()
+        L.alfa_dp_batch_cells.restype = C.c_int64
+        L.alfa_dp_batch_kernel_ms.restype = C.c_double
+
+    def launch(self):
+        check(lib().alfa_dp_batch_launch(self._h))
+
+    def fetch(self):
+        n = self.n
+        if self.mode == DP_EXTEND:
+            out = np.zeros(n, dtype=EXTEND_DTYPE)
+            check(lib().alfa_dp_batch_fetch(self._h, out.ctypes.data_as(C.c_void_p), None, None, None))
+            return out
+        out = np.zeros(n, dtype=np.int32)
+        if self.mode == DP_NW:
+            check(lib().alfa_dp_batch_fetch(self._h, out.ctypes.data_as(C.c_void_p), None, None, None))
+            return out
+        ncig = np.zeros(n, dtype=np.int32)
+        coff = np.zeros(n + 1, dtype=np.int64)
+        cptr = C.c_void_p()
+        check(lib().alfa_dp_batch_fetch(self._h, out.ctypes.data_as(C.c_void_p), C.byref(cptr), ncig.ctypes.data_as(C.c_void_p),
+                                        coff.ctypes.data_as(C.c_void_p)))
+        total = int(coff[-1])
+        cig = np.frombuffer(C.string_at(cptr.value, total * 4), dtype=np.uint32).copy() if total else np.zeros(0, np.uint32)
+        lib().alfa_free(cptr)
+        return out, cig, ncig, coff
+
+    @property
+    def cells(self):
+        return lib().alfa_dp_batch_cells(self._h)
+
+    @property
+    def kernel_ms(self):
+        return lib().alfa_dp_batch_kernel_ms(self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().alfa_dp_batch_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class SeedPlan:
+    def __init__(self, dev_index, mem_type, queries):
+        self.index = dev_index
+        self.nq = len(queries)
+        self._keep = queries
+        h = C.c_void_p()
+        check(lib().alfa_seed_plan_create(dev_index._h, int(mem_type), queries, self.nq, C.byref(h)))
+        self._h = h
+        L = lib()
+        L.alfa_seed_plan_queries.restype = C.c_int64
+        L.alfa_seed_plan_kernel_ms.restype = C.c_double
+
+    def launch(self):
+        check(lib().alfa_seed_plan_launch(self._h))
+
+    def fetch(self):
+        def fn(h, t, q, nq, m, o):
+            rc = lib().alfa_seed_plan_fetch(h, m, o)
+            check(rc)
+            return rc
+        return _seed_call(fn, self._h, 0, self._keep, lib().alfa_free)
+
+    @property
+    def queries(self):
+        return lib().alfa_seed_plan_queries(self._h)
+
+    @property
+    def kernel_ms(self):
+        return lib().alfa_seed_plan_kernel_ms(self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().alfa_seed_plan_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def sync(device=0):
+    check(lib().alfa_sync(int(device)))
+
+
+def timer_start(device=0):
+    check(lib().alfa_timer_start(int(device)))
+
+
+def timer_stop(device=0):
+    ms = C.c_double()
+    check(lib().alfa_timer_stop(int(device), C.byref(ms)))
+    return ms.value

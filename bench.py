@@ -1,0 +1,328 @@
+#!/usr/bin/env python3
+"""bench.py -- hot-path throughput of libalfa_hot on MI355X (see DESIGN.md "Measurement").
+
+One *step* = one pass of the seed-and-extend hot path over one resident batch of synthetic reads:
+  SMAM seed retrieval for both strands of every read (smam_count_kernel -> scan -> smam_emit_kernel)
+  + the banded-DP tasks of those reads (ksw_nw, ksw_extend, ksw_global kernels).
+All inputs of all steps are packed and copied to HBM before the timed region; the timed region only
+launches kernels (alfa_seed_plan_launch / alfa_dp_batch_launch) and is bracketed by barrier +
+torch.cuda.synchronize() + alfa_sync() on both sides.
+
+Workload = BASELINE.json configs[2] ("synthetic 5 Mbp random reference, 1M simulated 250 bp reads at
+2% error, 1 GPU"): the configuration the metric is quoted on that fits one GPU.  configs[0]/[1] are the
+48 kbp lambda-phage walkthrough files (parity cases, not bench lines).
+
+DP task shapes: until the staged host mapper feeds its own task stream into the bench, the DP tasks of a
+read are drawn from its true alignment with the per-read call census of the reference measured in
+SURVEY.md 6 (0.8 ksw_nw, 0.86 ksw_extend, 1.7 ksw_global calls per 250 bp read, bands from the
+mapper's formulas); this is stated in the JSON line under config.dp_tasks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD32 x 2.4 GHz = 78.6 T int32 lane-ops/s
+
+ACGT = np.frombuffer(b"acgt", dtype=np.uint8)
+_RC = bytes.maketrans(b"acgtn", b"tgcan")
+NT4 = np.full(256, 4, np.uint8)
+for _i, _c in enumerate(b"acgt"):
+    NT4[_c] = _i
+    NT4[_c - 32] = _i
+
+
+def make_reference(n, seed):
+    rng = np.random.default_rng(seed)
+    return ACGT[rng.integers(0, 4, n)]
+
+
+def simulate_batch(rng, ref, n, rlen, err):
+    """n reads: a window of rlen reference bases with per-base error err (60/20/20 sub/ins/del), 50/50 strand.
+    Returns (list of read bytes as sequenced, list of their reverse complements, true positions, strands)."""
+    L = len(ref)
+    pos = rng.integers(0, L - rlen - 64, n)
+    win = ref[pos[:, None] + np.arange(rlen)[None, :]]
+    r = rng.random((n, rlen))
+    sub = r < 0.6 * err
+    ins = (r >= 0.6 * err) & (r < 0.8 * err)
+    dele = (r >= 0.8 * err) & (r < err)
+    win[sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
+    reps = (1 + ins.astype(np.int8) - dele.astype(np.int8)).astype(np.int64)
+    flat = np.repeat(win.reshape(-1), reps.reshape(-1))
+    ends = np.cumsum(reps.reshape(-1))
+    ipos = ends[ins.reshape(-1)] - 1
+    flat[ipos] = ACGT[rng.integers(0, 4, len(ipos))]
+    row_end = ends.reshape(n, rlen)[:, -1]
+    row_beg = np.concatenate([[0], row_end[:-1]])
+    buf = flat.tobytes()
+    strand = rng.random(n) < 0.5
+    fw, rc = [], []
+    for i in range(n):
+        s = buf[row_beg[i]:row_end[i]]
+        t = s[::-1].translate(_RC)
+        if strand[i]:
+            fw.append(s); rc.append(t)
+        else:
+            fw.append(t); rc.append(s)
+    return fw, rc, pos, strand
+
+
+def census_dp_tasks(rng, ref_nt4, fw, rc, pos, strand, edit_dist):
+    """DP tasks per read following the call census of SURVEY.md 6 (see module docstring)."""
+    from alfalfa_amd import ffi
+    ext, nw, glob = [], [], []
+    ext_w, ext_h0, nw_w, glob_w = [], [], [], []
+    n = len(fw)
+    u = rng.random((n, 4))
+    lens = rng.integers(4, 60, (n, 4))
+    for i in range(n):
+        read = fw[i] if strand[i] else rc[i]          # the strand that matches the forward reference
+        rd = NT4[np.frombuffer(read, np.uint8)]
+        p = int(pos[i])
+        rl = len(rd)
+        if u[i, 0] < 0.86:   # one-sided extension: read overhang vs reference window of qlen+editDist
+            ql = int(lens[i, 0])
+            q = rd[rl - ql:]
+            t = ref_nt4[p + rl - ql - 2: p + rl + edit_dist]
+            ext.append((q, t)); ext_w.append(min(edit_dist, ql)); ext_h0.append(rl - ql)
+        if u[i, 1] < 0.8:    # inner chain gap
+            ql = int(lens[i, 1]); a = int(rng.integers(0, rl - ql))
+            q = rd[a:a + ql]
+            t = ref_nt4[p + a: p + a + ql + int(rng.integers(0, 3))]
+            nw.append((q, t)); nw_w.append(abs(len(q) - len(t)) + 3 + 3)
+        for k in (2, 3):     # CIGAR recovery gaps (1.7 per read)
+            if u[i, k] < 0.85:
+                ql = int(lens[i, k]); a = int(rng.integers(0, rl - ql))
+                q = rd[a:a + ql]
+                t = ref_nt4[p + a: p + a + ql + int(rng.integers(0, 3))]
+                glob.append((q, t)); glob_w.append(abs(len(q) - len(t)) + 3 + 4)
+    te, ke = ffi.make_dp_tasks(ext, ext_w, ext_h0)
+    tn, kn = ffi.make_dp_tasks(nw, nw_w, 0)
+    tg, kg = ffi.make_dp_tasks(glob, glob_w, 0)
+    return (te, ke), (tn, kn), (tg, kg)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=100000, help="reads per step per GPU")
+    ap.add_argument("--ref-len", type=int, default=5000000)
+    ap.add_argument("--read-len", type=int, default=250)
+    ap.add_argument("--err", type=float, default=0.02)
+    ap.add_argument("--sparseness", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=20000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = local_rank if world > 1 else 0
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libalfa_hot has no CPU fallback")
+    torch.cuda.set_device(dev)
+
+    from alfalfa_amd import ffi
+    import seqgen
+    K = args.sparseness
+    ref = make_reference(args.ref_len, 1)        # PRNG seed 1 for C3
+    ref_bytes = ref.tobytes()
+    ref_nt4 = NT4[ref]
+    t0 = time.time()
+    hidx = ffi.HostIndex.build_mem(["chr1"], [ref_bytes], K=K)
+    didx = ffi.DeviceIndex(hidx, dev)
+    t_index = time.time() - t0
+
+    err_percent = 0.08                           # reference default (src/options.cpp:52)
+    min_len, sparse_q = seqgen.seed_params(K, args.read_len, err_percent)
+    edit_dist = int(err_percent * args.read_len) + 1
+    P = ffi.default_params()
+    nsteps = args.warmup + args.steps
+    rng = np.random.default_rng(1000 + rank)
+    steps = []
+    sample = None
+    for s in range(nsteps):
+        fw, rc, pos, strand = simulate_batch(rng, ref, args.batch, args.read_len, args.err)
+        queries = ffi.make_seed_queries(fw + rc, min_len, 10000, sparse_q)
+        plan = ffi.SeedPlan(didx, ffi.SEED_SMAM, queries)
+        (te, ke), (tn, kn), (tg, kg) = census_dp_tasks(rng, ref_nt4, fw, rc, pos, strand, edit_dist)
+        b_ext = ffi.DpBatch(ffi.DP_EXTEND, P, te, dev)
+        b_nw = ffi.DpBatch(ffi.DP_NW, P, tn, dev)
+        b_gl = ffi.DpBatch(ffi.DP_GLOBAL, P, tg, dev)
+        steps.append((plan, b_ext, b_nw, b_gl))
+        if s == 0:
+            sample = (fw, rc, te, tn, tg, (ke, kn, kg))
+        else:
+            del fw, rc
+
+    def run(step):
+        plan, b_ext, b_nw, b_gl = step
+        plan.launch(); b_nw.launch(); b_ext.launch(); b_gl.launch()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for s in range(args.warmup):
+        run(steps[s])
+    ffi.sync(dev)
+    torch.cuda.synchronize()
+    barrier()
+    ffi.sync(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ffi.timer_start(dev)
+    for s in range(args.warmup, nsteps):
+        run(steps[s])
+    dev_ms = ffi.timer_stop(dev)
+    ffi.sync(dev)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    timed = steps[args.warmup:]
+    seed_ms = [st[0].kernel_ms for st in timed]
+    ext_ms = [st[1].kernel_ms for st in timed]
+    nw_ms = [st[2].kernel_ms for st in timed]
+    gl_ms = [st[3].kernel_ms for st in timed]
+    cells_ext = sum(st[1].cells for st in timed)
+    cells_nw = sum(st[2].cells for st in timed)
+    cells_gl = sum(st[3].cells for st in timed)
+    queries_per_step = timed[0][0].queries
+
+    # correctness spot check of one timed step against nothing but itself being fetched (parity lives in tests/)
+    m, off = timed[0][0].fetch()
+    seeds_per_read = len(m) / args.batch
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- algorithmic bytes of the dominant kernel (SURVEY 8d census, counted by the oracle on a sample)
+    import oracle_ffi as O
+    fw, rc, te, tn, tg, _keep = sample
+    ns = min(2000, len(fw))
+    O.orc_counters_reset()
+    qs = ffi.make_seed_queries(fw[:ns] + rc[:ns], min_len, 10000, sparse_q)
+    O.orc_seed_batch(hidx.view, ffi.SEED_SMAM, qs)
+    c = O.orc_counters()
+    bytes_per_read = c["sa_bytes"] / ns
+    bytes_per_launch = bytes_per_read * args.batch
+    seed_avg_ms = float(np.mean(seed_ms))
+    achieved = bytes_per_launch / (seed_avg_ms * 1e-3) / 1e9
+
+    # HBM-side bytes per dispatch of that kernel from the committed rocprofv3 --pmc FETCH_SIZE pass (profiles/),
+    # valid only for the batch size it was collected at; null otherwise
+    traffic = None
+    try:
+        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+        if prof:
+            pj = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
+            if pj.get("batch") == args.batch and args.ref_len == 5000000 and args.read_len == 250:
+                traffic = pj["bytes_per_dispatch"].get("smam_count_kernel")
+    except Exception:
+        traffic = None
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        # the oracle (scalar port) on one host core over a bounded sample of the same workload
+        nsamp = min(args.cpu_sample, len(fw))
+        frac = nsamp / len(fw)
+        qs = ffi.make_seed_queries(fw[:nsamp] + rc[:nsamp], min_len, 10000, sparse_q)
+        ne, nn, ng = int(len(te) * frac), int(len(tn) * frac), int(len(tg) * frac)
+        tc0 = time.perf_counter()
+        O.orc_seed_batch(hidx.view, ffi.SEED_SMAM, qs)
+        tseed = time.perf_counter() - tc0
+        O.orc_counters_reset()
+        O.orc_ksw_extend_batch(P, (ffi.DpTask * ne).from_address(C_addr(te)))
+        O.orc_ksw_nw_batch(P, (ffi.DpTask * nn).from_address(C_addr(tn)))
+        O.orc_ksw_global_batch(P, (ffi.DpTask * ng).from_address(C_addr(tg)))
+        tcpu = time.perf_counter() - tc0
+        cc = O.orc_counters()
+        cpu_cells = cc["cells_extend"] + cc["cells_nw"] + cc["cells_global"]
+        cpu = {"value": nsamp / tcpu, "unit": "reads/s", "cores": 1, "kind": "port",
+               "sample": "%d reads (both strands seeded + their DP tasks) of step 0, oracle/liboracle.so, 1 thread" % nsamp,
+               "seed_reads_per_s": nsamp / tseed, "dp_gcups": cpu_cells / max(tcpu - tseed, 1e-9) / 1e9}
+
+    total_reads = args.batch * args.steps * world
+    dp_ms = sum(ext_ms) + sum(nw_ms) + sum(gl_ms)
+    out = {
+        "metric": "mapped reads/sec (hot path: SMAM seeds both strands + banded DP) + banded-DP GCUPS",
+        "value": total_reads / elapsed,
+        "unit": "reads/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8/int32",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[2]: %d bp iid random reference, %d-bp reads at %.0f%% error (60/20/20 sub/ins/del), "
+                        "index sparseness K=%d, %d reads per step per GPU, %d timed steps" %
+                        (args.ref_len, args.read_len, args.err * 100, K, args.batch, args.steps),
+            "seed_type": "SMAM (CLI --seed SMEM default), min_len=%d sparseQ=%d maxCount=10000, fw+rc" % (min_len, sparse_q),
+            "dp_tasks": "per-read call census of SURVEY.md 6 drawn from the true alignment (0.86 ksw_extend, 0.8 ksw_nw, "
+                        "1.7 ksw_global per read); host mapper not in the timed region",
+            "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world,
+        },
+        "device_ms_total": dev_ms,
+        "dp_gcups": (cells_ext + cells_nw + cells_gl) / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else None,
+        "dp_detail": {
+            "extend": {"cells": cells_ext, "ms": sum(ext_ms), "gcups": cells_ext / max(sum(ext_ms), 1e-9) / 1e6},
+            "nw": {"cells": cells_nw, "ms": sum(nw_ms), "gcups": cells_nw / max(sum(nw_ms), 1e-9) / 1e6},
+            "global": {"cells": cells_gl, "ms": sum(gl_ms), "gcups": cells_gl / max(sum(gl_ms), 1e-9) / 1e6},
+            "valu_frac_extend": cells_ext * 12 / max(sum(ext_ms) * 1e-3, 1e-12) / 1e12 / VALU_PEAK_TOPS,
+        },
+        "seed_queries_per_step": queries_per_step,
+        "seeds_per_read": seeds_per_read,
+        "index_build_s": t_index,
+        "roofline": {
+            "kernel": "smam_count_kernel",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "algorithmic_bytes_per_read": bytes_per_read,
+            "avg_launch_ms": seed_avg_ms,
+        },
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def C_addr(arr):
+    import ctypes
+    return ctypes.addressof(arr)
+
+
+if __name__ == "__main__":
+    main()

@@ -151,6 +151,41 @@ typedef struct {
 int  alfa_dp_band_batch(int variant, const alfa_dpband_scores* s, const alfa_dpband_task* t, int n,
                         alfa_dpband_result* r, char** cig_chars, int32_t** cig_lens);
 
+/* --- resident batches ---------------------------------------------------- */
+/* The synchronous entry points above are create + launch + fetch of the objects below.
+ * A staged caller (the batch mapper, bench.py) keeps batches resident in HBM and
+ * separates the three phases: create() packs the inputs and copies them to the device
+ * (synchronous), launch() only enqueues the kernels on the calling thread's stream for
+ * that device (asynchronous, no allocation, no host synchronisation) and fetch() waits,
+ * copies the results back and unpacks them exactly like the synchronous call.
+ * No counterpart in the reference (it has no device); semantics are those of the
+ * corresponding synchronous call. */
+typedef struct alfa_dp_batch alfa_dp_batch;
+#define ALFA_DP_NW     0
+#define ALFA_DP_GLOBAL 1
+#define ALFA_DP_EXTEND 2
+int     alfa_dp_batch_create(int mode, const alfa_dp_params* p, const alfa_dp_task* t, int n, int device, alfa_dp_batch** out);
+int     alfa_dp_batch_launch(alfa_dp_batch*);
+/* out: alfa_extend_result[n] (EXTEND) or int32 score[n]; cigar/n_cigar/cig_off as alfa_ksw_global_batch (GLOBAL only, else NULL) */
+int     alfa_dp_batch_fetch(alfa_dp_batch*, void* out, uint32_t** cigar, int32_t* n_cigar, int64_t* cig_off);
+int64_t alfa_dp_batch_cells(const alfa_dp_batch*);       /* inner-loop cells of the static band envelope */
+double  alfa_dp_batch_kernel_ms(const alfa_dp_batch*);   /* HIP-event time of the last launch's kernels (after fetch/sync) */
+void    alfa_dp_batch_free(alfa_dp_batch*);
+
+typedef struct alfa_seed_plan alfa_seed_plan;
+int     alfa_seed_plan_create(alfa_index*, int mem_type, const alfa_seed_query* q, int nq, alfa_seed_plan** out);
+int     alfa_seed_plan_launch(alfa_seed_plan*);
+int     alfa_seed_plan_fetch(alfa_seed_plan*, alfa_match** matches, int64_t* offsets);
+int64_t alfa_seed_plan_queries(const alfa_seed_plan*);   /* number of (read,prefix) traversals */
+double  alfa_seed_plan_kernel_ms(const alfa_seed_plan*); /* HIP-event time of the traversal kernel of the last launch */
+void    alfa_seed_plan_free(alfa_seed_plan*);
+
+/* wait for everything enqueued on the calling thread's stream for `device` */
+int     alfa_sync(int device);
+/* HIP-event stopwatch on that same stream: start, (launch...), stop -> elapsed device milliseconds */
+int     alfa_timer_start(int device);
+int     alfa_timer_stop(int device, double* ms);
+
 /* --- misc --------------------------------------------------------------- */
 void        alfa_free(void*);            /* every library-allocated host buffer */
 const char* alfa_last_error(void);       /* thread-local, human readable */
