@@ -1,0 +1,42 @@
+"""CPU tests (no GPU): pin the oracle against the golden vectors generated from the compiled reference."""
+import numpy as np
+import pytest
+
+from alfalfa_amd import ffi
+import oracle_ffi as O
+import golden_util as G
+
+
+def _seed_fn(hidx, mt, q):
+    return O.orc_seed_batch(hidx.view, mt, q)
+
+
+@pytest.mark.parametrize("K", [1, 12])
+def test_oracle_seeds_all_types(K):
+    assert G.check_seeds(_seed_fn, K) > 1000
+
+
+def test_oracle_ksw_mapper_calls():
+    assert G.check_ksw_calls(O.orc_ksw_extend_batch, O.orc_ksw_nw_batch, O.orc_ksw_global_batch) > 3000
+
+
+def test_oracle_ksw_random_edge_cases():
+    assert G.check_ksw_random(O.orc_ksw_extend_batch, O.orc_ksw_nw_batch, O.orc_ksw_global_batch) == 1500
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref (compiled reference) only exists in the build container")
+def test_oracle_vs_live_reference_nochild_and_suflink():
+    """index variants the fixtures do not cover: --no-child (binary-search traverse) and --suflink"""
+    import seqgen
+    rng = np.random.default_rng(77)
+    ref = seqgen.rand_ref(rng, 40000)
+    ref = ref + ref[1000:3000] + seqgen.rand_ref(rng, 5000)
+    reads = seqgen.sim_reads(rng, ref, 40, 80, 600, 0.03)
+    for K, suf, child in ((1, False, False), (3, True, True), (4, True, False), (12, False, False)):
+        mine = ffi.HostIndex.build_mem(["x"], [ref], K=K, suflink=suf, child=child)
+        rix = O.RefIndex.build_mem(["x"], [ref], K=K, suflink=suf, child=child)
+        for mt in ((0, 1) if not child else (0, 1, 2, 3)):
+            q = ffi.make_seed_queries(reads, 30, 1000, 1, 10)
+            m, off = O.orc_seed_batch(mine.view, mt, q)
+            for i, r in enumerate(reads):
+                assert np.array_equal(m[off[i]:off[i + 1]], rix.seed(mt, r, 30, 1000, 1, 10)), (K, suf, child, mt, i)
