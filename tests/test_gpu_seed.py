@@ -63,6 +63,15 @@ def test_smam_repeats_multi_contig(gpu):
         _check(hidx, didx, reads, 25, 2, 1)
 
 
+def test_smam_index_without_kmer_table(gpu):
+    rng = np.random.default_rng(8)
+    ref = seqgen.rand_ref(rng, 60000)
+    hidx = ffi.HostIndex.build_mem(["x"], [ref], K=3, kmer=False)
+    didx = ffi.DeviceIndex(hidx, gpu)
+    reads = seqgen.sim_reads(rng, ref, 100, 60, 400, 0.03)
+    assert _check(hidx, didx, reads, 30, 1000, 2) > 50
+
+
 def test_unsupported_types_fail_loudly(gpu):
     rng = np.random.default_rng(5)
     ref = seqgen.rand_ref(rng, 20000)
