@@ -1,0 +1,27 @@
+// alfalfa_main.cpp -- `alfalfa_amd`: the reference's `alfalfa index|align` commands on top of libalfa_hot (HIP only).
+#include <hip/hip_runtime.h>
+
+#include "mapper_cli.h"
+
+int main(int argc, char** argv) {
+    alfa::HotBinding b;
+    b.make_ops = [](int device, const alfa_host_index* hidx, alfa::HotOps* ops) {
+        alfa_index* dix = nullptr;
+        int rc = alfa_index_upload(alfa_host_index_view(hidx), device, &dix);
+        if (rc) return rc;
+        ops->index = dix;
+        ops->seed_batch = [](void* ix, int type, const alfa_seed_query* q, int nq, alfa_match** m, int64_t* off) {
+            return alfa_seed_batch((alfa_index*)ix, type, q, nq, m, off);
+        };
+        ops->ksw_extend_batch = alfa_ksw_extend_batch;
+        ops->ksw_nw_batch = alfa_ksw_nw_batch;
+        ops->ksw_global_batch = alfa_ksw_global_batch;
+        ops->free_fn = alfa_free;
+        ops->last_error = alfa_last_error;
+        return 0;
+    };
+    b.release_ops = [](alfa::HotOps* ops) { alfa_index_free((alfa_index*)ops->index); };
+    b.bind_thread = [](int device) { (void)hipSetDevice(device); };
+    b.last_error = alfa_last_error;
+    return alfa::mapper_main(argc, argv, b);
+}

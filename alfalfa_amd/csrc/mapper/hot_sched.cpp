@@ -1,0 +1,155 @@
+// hot_sched.cpp -- see hot_sched.h
+#include "hot_sched.h"
+
+#include <sys/mman.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+namespace alfa {
+
+HotSched::HotSched(const HotOps& ops, const alfa_dp_params& prm, size_t stack_bytes) : ops_(ops), prm_(prm), stack_bytes_(stack_bytes) {}
+
+HotSched::~HotSched() {
+    for (auto& f : fibers_)
+        if (f.stack) munmap(f.stack, stack_bytes_);
+}
+
+void HotSched::trampoline(unsigned lo, unsigned hi) {
+    HotSched* self = (HotSched*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    Fiber& f = self->fibers_[self->current_];
+    (*self->job_)(f.job);
+    f.done = true;
+    swapcontext(&f.ctx, &self->main_ctx_);
+}
+
+void HotSched::wait() {
+    Fiber& f = fibers_[current_];
+    swapcontext(&f.ctx, &main_ctx_);
+}
+
+static void die(const HotOps& ops, const char* what, int rc) {
+    fprintf(stderr, "ERROR: %s failed (%d): %s\n", what, rc, ops.last_error ? ops.last_error() : "");
+    exit(1);
+}
+
+void HotSched::flush() {
+    auto t0 = std::chrono::steady_clock::now();
+    stats_.rounds++;
+    if (!seed_.empty()) {
+        // group by seed type (one batch call per type)
+        for (int type = 0; type < 4; ++type) {
+            std::vector<alfa_seed_query> q;
+            std::vector<size_t> who;
+            for (size_t i = 0; i < seed_.size(); ++i)
+                if (seed_[i].mem_type == type) {
+                    const SeedReq& r = seed_[i];
+                    q.push_back(alfa_seed_query{r.P->data(), (int32_t)r.P->size(), r.min_len, r.max_count, r.sparse_q, r.max_smem});
+                    who.push_back(i);
+                }
+            if (q.empty()) continue;
+            alfa_match* m = nullptr;
+            std::vector<int64_t> off(q.size() + 1);
+            int rc = ops_.seed_batch(ops_.index, type, q.data(), (int)q.size(), &m, off.data());
+            if (rc) die(ops_, "alfa_seed_batch", rc);
+            for (size_t k = 0; k < who.size(); ++k) {
+                std::vector<Match>* out = seed_[who[k]].out;
+                for (int64_t j = off[k]; j < off[k + 1]; ++j) out->push_back(Match{m[j].ref, m[j].query, m[j].len});
+            }
+            ops_.free_fn(m);
+            stats_.seed_calls++;
+            stats_.seed_queries += (int64_t)q.size();
+        }
+        seed_.clear();
+    }
+    if (!nw_.empty()) {
+        std::vector<alfa_dp_task> t(nw_.size());
+        std::vector<int32_t> s(nw_.size());
+        for (size_t i = 0; i < nw_.size(); ++i) t[i] = nw_[i].t;
+        int rc = ops_.ksw_nw_batch(&prm_, t.data(), (int)t.size(), s.data());
+        if (rc) die(ops_, "alfa_ksw_nw_batch", rc);
+        for (size_t i = 0; i < nw_.size(); ++i) *nw_[i].out = s[i];
+        stats_.nw_calls++; stats_.nw_tasks += (int64_t)nw_.size();
+        nw_.clear();
+    }
+    if (!ext_.empty()) {
+        std::vector<alfa_dp_task> t(ext_.size());
+        std::vector<alfa_extend_result> r(ext_.size());
+        for (size_t i = 0; i < ext_.size(); ++i) t[i] = ext_[i].t;
+        int rc = ops_.ksw_extend_batch(&prm_, t.data(), (int)t.size(), r.data());
+        if (rc) die(ops_, "alfa_ksw_extend_batch", rc);
+        for (size_t i = 0; i < ext_.size(); ++i) *ext_[i].out = r[i];
+        stats_.ext_calls++; stats_.ext_tasks += (int64_t)ext_.size();
+        ext_.clear();
+    }
+    if (!glob_.empty()) {
+        std::vector<alfa_dp_task> t(glob_.size());
+        std::vector<int32_t> s(glob_.size()), nc(glob_.size());
+        std::vector<int64_t> off(glob_.size() + 1);
+        for (size_t i = 0; i < glob_.size(); ++i) t[i] = glob_[i].t;
+        uint32_t* cig = nullptr;
+        int rc = ops_.ksw_global_batch(&prm_, t.data(), (int)t.size(), s.data(), &cig, nc.data(), off.data());
+        if (rc) die(ops_, "alfa_ksw_global_batch", rc);
+        for (size_t i = 0; i < glob_.size(); ++i) {
+            *glob_[i].score = s[i];
+            glob_[i].cigar->clear();
+            if (nc[i] > 0) glob_[i].cigar->assign(cig + off[i], cig + off[i] + nc[i]);
+        }
+        ops_.free_fn(cig);
+        stats_.glob_calls++; stats_.glob_tasks += (int64_t)glob_.size();
+        glob_.clear();
+    }
+    stats_.hot_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void HotSched::run(int n, int max_fibers, const std::function<void(int)>& job) {
+    if (n <= 0) return;
+    job_ = &job;
+    const int nf = std::min(n, std::max(1, max_fibers));
+    while ((int)fibers_.size() < nf) {
+        Fiber f;
+        f.stack = (char*)mmap(nullptr, stack_bytes_, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+        if (f.stack == (char*)MAP_FAILED) throw std::runtime_error("mmap of a fiber stack failed");
+        fibers_.push_back(f);
+    }
+    int next = 0, live = 0;
+    auto start = [&](int fi) {
+        Fiber& f = fibers_[fi];
+        f.done = false;
+        f.job = next++;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = stack_bytes_;
+        f.ctx.uc_link = nullptr;
+        uintptr_t p = (uintptr_t)this;
+        makecontext(&f.ctx, (void (*)())trampoline, 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
+        live++;
+    };
+    for (int fi = 0; fi < nf; ++fi) start(fi);
+    while (live > 0) {
+        // resume every live fiber once: each either finishes or parks in wait() after submitting requests
+        for (int fi = 0; fi < nf; ++fi) {
+            Fiber& f = fibers_[fi];
+            if (f.done) {
+                if (next >= n) continue;
+                start(fi);               // recycle the fiber for the next read
+            }
+            for (;;) {
+                current_ = fi;
+                swapcontext(&main_ctx_, &f.ctx);
+                if (!f.done) break;      // parked in wait()
+                live--;
+                if (next >= n) break;
+                start(fi);               // finished: take the next read right away
+            }
+        }
+        flush();
+    }
+    current_ = -1;
+    job_ = nullptr;
+}
+
+}  // namespace alfa

@@ -1,0 +1,82 @@
+// hot_sched.h -- fiber scheduler that turns the mapper's per-read, synchronous-looking hot-path calls
+// (sa.SMAM(...), ksw_extend(...), ksw_nw(...), ksw_global(...)) into large batches for libalfa_hot.
+//
+// The reference maps one read per kt_for work item and calls the hot path synchronously
+// (src/main.cpp:87-104,126).  A GPU needs >=10^4 independent calls in flight, so every read is mapped
+// inside its own stackful fiber (ucontext): a hot-path call records a request and yields; when all
+// fibers of a worker thread are parked the scheduler issues ONE batch call per request kind through the
+// C ABI (include/alfa_hot.h), scatters the results and resumes the fibers.  The mapper code therefore
+// keeps the reference's call structure (and its data-dependent control flow) unchanged.
+#pragma once
+#include <ucontext.h>
+
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../../include/alfa_hot.h"
+
+namespace alfa {
+
+// The one seam between the host mapper and the hot path: the batch entry points of include/alfa_hot.h.
+// The product binds them to libalfa_hot (HIP); tests/ may bind a checker with the same signatures.
+struct HotOps {
+    void* index = nullptr;   // alfa_index* (what seed_batch expects as its first argument)
+    int (*seed_batch)(void*, int, const alfa_seed_query*, int, alfa_match**, int64_t*) = nullptr;
+    int (*ksw_extend_batch)(const alfa_dp_params*, const alfa_dp_task*, int, alfa_extend_result*) = nullptr;
+    int (*ksw_nw_batch)(const alfa_dp_params*, const alfa_dp_task*, int, int32_t*) = nullptr;
+    int (*ksw_global_batch)(const alfa_dp_params*, const alfa_dp_task*, int, int32_t*, uint32_t**, int32_t*, int64_t*) = nullptr;
+    void (*free_fn)(void*) = nullptr;
+    const char* (*last_error)() = nullptr;
+};
+
+struct Match { int64_t ref; int32_t query; int32_t len; };   // == match_t / alfa_match
+
+struct SeedReq {
+    const std::string* P; int min_len, max_count, sparse_q, mem_type, max_smem; std::vector<Match>* out;
+};
+struct ExtendReq { alfa_dp_task t; alfa_extend_result* out; };
+struct NwReq { alfa_dp_task t; int32_t* out; };
+struct GlobalReq { alfa_dp_task t; int32_t* score; std::vector<uint32_t>* cigar; };
+
+struct SchedStats {
+    int64_t rounds = 0, seed_calls = 0, seed_queries = 0, ext_calls = 0, ext_tasks = 0, nw_calls = 0, nw_tasks = 0, glob_calls = 0,
+            glob_tasks = 0;
+    double hot_seconds = 0;   // wall time spent inside the batch entry points
+};
+
+class HotSched {
+   public:
+    HotSched(const HotOps& ops, const alfa_dp_params& prm, size_t stack_bytes = 256 * 1024);
+    ~HotSched();
+    // runs job(i) for i in [0,n) with at most `max_fibers` in flight; jobs call the submit_*/wait API below
+    void run(int n, int max_fibers, const std::function<void(int)>& job);
+
+    // ---- called from inside a job
+    void submit_seed(const SeedReq& r) { seed_.push_back(r); }
+    void submit_extend(const ExtendReq& r) { ext_.push_back(r); }
+    void submit_nw(const NwReq& r) { nw_.push_back(r); }
+    void submit_global(const GlobalReq& r) { glob_.push_back(r); }
+    void wait();              // returns when every request submitted by this fiber has been answered
+    const SchedStats& stats() const { return stats_; }
+
+   private:
+    struct Fiber { ucontext_t ctx; char* stack = nullptr; bool done = true; int job = -1; };
+    static void trampoline(unsigned lo, unsigned hi);
+    void flush();
+    HotOps ops_;
+    alfa_dp_params prm_;
+    size_t stack_bytes_;
+    std::vector<Fiber> fibers_;
+    ucontext_t main_ctx_;
+    int current_ = -1;
+    const std::function<void(int)>* job_ = nullptr;
+    std::vector<SeedReq> seed_;
+    std::vector<ExtendReq> ext_;
+    std::vector<NwReq> nw_;
+    std::vector<GlobalReq> glob_;
+    SchedStats stats_;
+};
+
+}  // namespace alfa

@@ -1,0 +1,927 @@
+// mapper.cpp -- see mapper.h.  Host logic around the hot path with the reference's semantics.
+#include "mapper.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <map>
+#include <sstream>
+
+namespace alfa {
+
+namespace {
+
+const int MIN_SEED_LENGTH = 20;   // src/mapper.cpp:36
+const int MAX_MAPQ = 60;          // :37
+const int64_t MAX_OVERLAP = -10;  // :38
+
+// Utils::ORDVALUE src/utils.h:55-80
+inline uint8_t nt4(unsigned char c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return 4;
+    }
+}
+
+// Utils::RC_TABLE src/utils.h:28-53
+struct RcTable {
+    char t[256];
+    RcTable() {
+        for (int i = 0; i < 256; ++i) t[i] = 'n';
+        for (int i = 65; i <= 96; ++i) t[i] = 'N';
+        const char* from = "ABCDGHKMRSTVWY";
+        const char* to = "TVGHCDMKYSABWR";
+        for (int i = 0; from[i]; ++i) { t[(int)from[i]] = to[i]; t[(int)from[i] + 32] = (char)(to[i] + 32); }
+    }
+};
+const RcTable RC;
+
+// bandSizeEstimate src/mapper.cpp:44-52
+int band_estimate(int fixedBand, int qLen, int refLen, int matchScore, int gapOpen, int gapExtend, int alnScore) {
+    int minBand = std::max(qLen - refLen, refLen - qLen) + 3;
+    int scoreBand = (std::min(qLen, refLen) * matchScore - alnScore + gapOpen) / (-1 * gapExtend) + 1;
+    int maxGapBand = minBand - 3 + ((qLen >> 1) * matchScore + gapOpen) / (-1 * gapExtend) + 1;
+    int band = std::min(maxGapBand, scoreBand);
+    band = std::min(fixedBand, band);
+    band = std::max(minBand, band);
+    return band;
+}
+
+// recoverCIGAR4 src/mapper.cpp:80-117 (also the body of setFieldsKsw :128-162)
+int cigar4(const std::vector<uint32_t>& bam, const uint8_t* query, const uint8_t* rseq, std::ostringstream& sNM, std::ostringstream* sCig) {
+    int x = 0, y = 0, n_mm = 0, n_gap = 0;
+    for (size_t k = 0; k < bam.size(); ++k) {
+        int op = bam[k] & 0xf;
+        int len = (int)(bam[k] >> 4);
+        if (sCig) *sCig << len << "MIDSH"[op];
+        if (op == 0) {
+            int matchLen = 0, mmLen = 0;
+            for (int i = 0; i < len; i++) {
+                if (query[x + i] != rseq[y + i]) {
+                    ++n_mm; ++mmLen;
+                    if (matchLen) { sNM << matchLen << "="; matchLen = 0; }
+                } else {
+                    ++matchLen;
+                    if (mmLen) { sNM << mmLen << "X"; mmLen = 0; }
+                }
+            }
+            if (matchLen) sNM << matchLen << "=";
+            else sNM << mmLen << "X";
+            x += len; y += len;
+        } else {
+            sNM << len << "MIDSH"[op];
+            if (op == 1) { x += len; n_gap += len; }
+            else if (op == 2) { y += len; n_gap += len; }
+        }
+    }
+    return n_mm + n_gap;
+}
+
+// recoverCIGAR3from4 src/mapper.cpp:54-77
+std::string cigar3_from4(const std::string& c4) {
+    std::ostringstream out;
+    size_t p = 0;
+    long matchLength = 0;
+    while (p < c4.size()) {
+        size_t q = p;
+        while (q < c4.size() && c4[q] >= '0' && c4[q] <= '9') q++;
+        if (q == p || q >= c4.size()) break;
+        int n = atoi(c4.substr(p, q - p).c_str());
+        char sym = c4[q];
+        if (sym == 'X' || sym == '=') matchLength += n;
+        else {
+            if (matchLength > 0) { out << matchLength << 'M'; matchLength = 0; }
+            out << n << sym;
+        }
+        p = q + 1;
+    }
+    if (matchLength > 0) out << matchLength << 'M';
+    return out.str();
+}
+
+bool cmp_matches(const Match& i, const Match& j) { return i.ref < j.ref || (i.ref == j.ref && i.query < j.query); }            // compMatches :570
+bool cmp_matches_smem(const Match& i, const Match& j) { return i.query < j.query || (i.query == j.query && i.len > j.len); }  // compMatchesSMEM :574
+bool cmp_matches_query(const Match& i, const Match& j) { return i.query < j.query || (i.query == j.query && i.ref < j.ref); } // compMatchesQuery mapper.h:37
+bool cmp_aln(const Alignment* i, const Alignment* j) { return i->alignmentScore > j->alignmentScore; }                          // compAlignments :295
+bool cmp_aln_paired(const Alignment* i, const Alignment* j) {                                                                   // compPairedAlignments :299
+    return i->alignmentScore + i->mate.alignmentScore > j->alignmentScore + j->mate.alignmentScore;
+}
+
+struct Bounds { int64_t refB, refE; int queryB, queryE; };
+
+}  // namespace
+
+void AlignOpt::fill_m() {
+    int k = 0;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 4; ++j) mat[k++] = (int8_t)(i == j ? match : mismatch);
+        mat[k++] = -1;
+    }
+    for (int j = 0; j < 5; ++j) mat[k++] = -1;
+}
+
+Read::~Read() {
+    for (Alignment* a : alignments) delete a;
+}
+Read::Read(Read&& o) noexcept
+    : qname(std::move(o.qname)), sequence(std::move(o.sequence)), qual(std::move(o.qual)), rcSequence(std::move(o.rcSequence)),
+      rQual(std::move(o.rQual)), readP(std::move(o.readP)), rcReadP(std::move(o.rcReadP)), alignments(std::move(o.alignments)),
+      pairedAlignmentCount(o.pairedAlignmentCount) {
+    o.alignments.clear();
+}
+
+void Read::init() {
+    rcSequence = sequence;
+    std::reverse(rcSequence.begin(), rcSequence.end());
+    for (auto& c : rcSequence) c = RC.t[(unsigned char)c];
+    rQual = qual;
+    std::reverse(rQual.begin(), rQual.end());
+    readP.resize(sequence.size());
+    rcReadP.resize(sequence.size());
+    for (size_t i = 0; i < sequence.size(); ++i) {
+        readP[i] = nt4((unsigned char)sequence[i]);
+        rcReadP[i] = nt4((unsigned char)rcSequence[i]);
+    }
+}
+
+// read_t::emptyAlingment src/mapper.h:170-179
+std::string Read::emptyAlignment(bool paired, bool mateFailed, bool upstream) const {
+    std::ostringstream ss;
+    int flag = 4;
+    if (paired) flag += 1;
+    if (mateFailed) flag += 8;
+    if (paired && upstream) flag += 64;
+    if (paired && !upstream) flag += 128;
+    ss << qname << "\t" << flag << "\t*\t0\t0\t*\t*\t0\t0\t" << sequence << "\t" << qual << "\n";
+    return ss.str();
+}
+
+// read_t::printUnpairedAlignment src/mapper.h:181-193
+std::string Read::printUnpaired(int i) const {
+    std::ostringstream ss;
+    const Alignment* a = alignments[i];
+    ss << qname << "\t" << (unsigned long)a->flag << "\t" << a->rname << "\t" << a->pos << "\t" << a->mapq << "\t" << a->cigar << "\t"
+       << "*" << "\t" << 0 << "\t" << 0 << "\t" << (a->rc() ? rcSequence : sequence) << "\t" << (a->rc() ? rQual : qual) << "\tAS:i:"
+       << a->alignmentScore << "\tNM:i:" << a->editDist << "\tX0:Z:" << a->NMtag << "\n";
+    return ss.str();
+}
+
+// read_t::printPairedAlignments src/mapper.h:196-215
+std::string Read::printPaired(int i, bool firstMate) {
+    Alignment* a = alignments[i];
+    if (a->paired()) {
+        std::ostringstream ss;
+        ss << qname << "\t" << (unsigned long)(a->flag | a->mate.flag) << "\t" << a->rname << "\t" << a->pos << "\t" << a->mapq << "\t"
+           << a->cigar << "\t" << (a->rname == a->mate.rnext ? "=" : a->mate.rnext) << "\t" << a->mate.pnext << "\t" << a->mate.tLength
+           << "\t" << (a->rc() ? rcSequence : sequence) << "\t" << (a->rc() ? rQual : qual) << "\tAS:i:"
+           << a->alignmentScore + a->mate.alignmentScore << "\tNM:i:" << a->editDist << "\tX0:Z:" << a->NMtag << "\n";
+        return ss.str();
+    }
+    // alignment_t::setUnPaired src/mapper.h:114-119
+    a->flag |= 1u;
+    if (firstMate) { a->flag |= 1u << 6; a->flag &= ~(1u << 7); }
+    else { a->flag &= ~(1u << 6); a->flag |= 1u << 7; }
+    a->flag |= 1u << 3;
+    return printUnpaired(i);
+}
+
+// createHeader src/main.cpp:266-283
+std::string sam_header(const RefIndex& idx, int argc, char** argv) {
+    std::ostringstream ss;
+    ss << "@HD\tVN:1.3\n";
+    const int n = idx.v->n_seq;
+    for (int i = 0; i + 1 < n; i++) ss << "@SQ\tSN:" << idx.descr(i) << "\tLN:" << (idx.v->startpos[i + 1] - idx.v->startpos[i] - 1) << "\n";
+    ss << "@SQ\tSN:" << idx.descr(n - 1) << "\tLN:" << (idx.v->N - idx.v->startpos[n - 1]) << "\n";   // includes the '$' padding
+    ss << "@PG\tID:alfalfa\tCL:";
+    for (int i = 0; i < argc; i++) { if (i > 0) ss << " "; ss << argv[i]; }
+    ss << "\tVN:0.8.1-mi355x\n";
+    return ss.str();
+}
+
+// ------------------------------------------------------------------------------------------ seeds
+// calculateSeedsBothStrands src/mapper.cpp:530-568
+void Mapper::seeds_both_strands(const std::string& P, const std::string& Prc, int min_len, std::vector<Match>& fw, std::vector<Match>& rc) {
+    const int K = (int)idx_.K();
+    int sparseSkip = 1;
+    if (K >= 4) sparseSkip = std::max((min_len - 10) / K, 1);
+    else sparseSkip = std::max((min_len - 12) / K, 1);
+    if (opt_.noSparseQ) sparseSkip = 1;
+    auto both = [&](int ml, int maxBranch, int skip) {
+        if (!opt_.noFW) hot_.submit_seed(SeedReq{&P, ml, maxBranch, skip, opt_.memType, opt_.maxSmemMemStart, &fw});
+        if (!opt_.noRC) hot_.submit_seed(SeedReq{&Prc, ml, maxBranch, skip, opt_.memType, opt_.maxSmemMemStart, &rc});
+        hot_.wait();
+    };
+    both(min_len, opt_.maxSeedCandidates, sparseSkip);
+    if (opt_.rescue && fw.empty() && rc.empty()) {
+        int minLength = std::max(MIN_SEED_LENGTH, K + 10);
+        both((minLength + min_len) / 2, 100000, 1);
+        if (fw.empty() && rc.empty()) both(minLength, 100000, 1);
+    }
+}
+
+// identifyAndFilter src/mapper.cpp:578-704
+void Mapper::identify_and_filter(std::vector<Match>& matches, bool fw, int qLength, int editDist, std::vector<Lis>& lis) {
+    if (matches.empty()) return;
+    const size_t emptySize = lis.size();
+    const size_t maxSmemOcc = (size_t)opt_.maxSeedCandidates;
+    const int64_t minMemLength = opt_.minMemRegLength;
+    const size_t maxPossOccIncrease = (size_t)opt_.maxRegionMems;
+    std::sort(matches.begin(), matches.end(), cmp_matches_smem);
+    std::vector<Match> smems, reserves;
+    smems.reserve(matches.size());
+    reserves.reserve(matches.size());
+    int64_t previousStart, previousEnd, previousREnd = -1;
+    size_t rangeStart = 0, currentSmemRange = 0, index = 0;
+    while (index < matches.size()) {
+        rangeStart = index;
+        previousStart = matches[index].query;
+        previousEnd = matches[index].query + matches[index].len;
+        index++;
+        while (index < matches.size() && matches[index].query == previousStart && matches[index].query + matches[index].len == previousEnd) index++;
+        if (previousEnd > previousREnd) currentSmemRange = index - rangeStart;
+        else currentSmemRange += index - rangeStart;
+        if ((previousEnd > previousREnd && currentSmemRange <= maxSmemOcc) ||
+            (currentSmemRange <= maxPossOccIncrease && previousEnd - previousStart >= minMemLength)) {
+            for (size_t j = rangeStart; j < index; j++) smems.push_back(matches[j]);
+        } else {
+            for (size_t j = rangeStart; j < index; j++) reserves.push_back(matches[j]);
+        }
+        previousREnd = previousEnd;
+    }
+    std::sort(smems.begin(), smems.end(), cmp_matches);
+    int begin = 0, end = 0, longest = 0;
+    int64_t refEnd, refBegin;
+    while (begin < (int)smems.size()) {
+        refEnd = smems[begin].ref - smems[begin].query + qLength + editDist;
+        longest = begin;
+        end = begin + 1;
+        while (end < (int)smems.size() && smems[end].ref + smems[end].len <= refEnd) {
+            if (smems[longest].len < smems[end].len) {
+                longest = end;
+                refEnd = smems[longest].ref - smems[longest].query + qLength + editDist;
+            }
+            end++;
+        }
+        refBegin = smems[longest].ref - smems[longest].query - editDist;
+        begin--;
+        const int beginFix = begin;
+        while (begin >= 0 && smems[begin].ref >= refBegin) begin--;
+        if (emptySize == lis.size() || lis.back().refEnd < refBegin) {
+            lis.push_back(Lis());
+            lis.back().fw = fw;
+            for (int i = begin + 1; i <= end - 1; i++) lis.back().matches.push_back(smems[i]);
+            lis.back().refBegin = refBegin;
+            lis.back().refEnd = refEnd;
+        } else {
+            for (int i = beginFix + 1; i <= end - 1; i++) lis.back().matches.push_back(smems[i]);
+            lis.back().refBegin = std::min(lis.back().refBegin, refBegin);
+            lis.back().refEnd = std::min(lis.back().refEnd, refEnd);     // the reference takes min for both ends (:673-674)
+        }
+        begin = end;
+    }
+    if (emptySize < lis.size()) {
+        std::sort(reserves.begin(), reserves.end(), cmp_matches);
+        size_t curReserve = 0, curInterval = emptySize;
+        while (curReserve < reserves.size() && curInterval < lis.size()) {
+            if (reserves[curReserve].ref < lis[curInterval].refBegin) curReserve++;
+            else if (lis[curInterval].refEnd < reserves[curReserve].ref) curInterval++;
+            else { lis[curInterval].matches.push_back(reserves[curReserve]); curReserve++; }
+        }
+    }
+}
+
+// coveredBases src/mapper.cpp:706-719
+static int covered_bases(std::vector<Match>& seeds) {
+    std::sort(seeds.begin(), seeds.end(), cmp_matches_query);
+    int trueCover = seeds[0].len;
+    int prevEnd = seeds[0].query + seeds[0].len - 1;
+    for (size_t i = 1; i < seeds.size(); i++) {
+        int start = std::max(seeds[i].query, prevEnd + 1);
+        int stop = std::max(prevEnd, seeds[i].query + seeds[i].len - 1);
+        prevEnd = stop;
+        trueCover += std::max(0, stop - start + 1);
+    }
+    return trueCover;
+}
+
+// calculateCandRegions src/mapper.cpp:1220-1267
+void Mapper::cand_regions(const Read& read, std::vector<Lis>& lis, double errorPercent) {
+    const std::string& P = read.sequence;
+    const std::string& Prc = read.rcSequence;
+    const int Plength = (int)P.length();
+    const int editDist = (int)(errorPercent * Plength) + 1;
+    int min_len = opt_.minMemLength;
+    if (!opt_.fixedMinLength && Plength >= 1000) min_len += (20 * ((int)(Plength / 500))) / ((int)100 * errorPercent);
+    if (opt_.fixedMinLength && Plength / editDist > min_len) min_len = Plength / editDist;
+    std::vector<Match> matches, matchesRC;
+    seeds_both_strands(P, Prc, min_len, matches, matchesRC);
+    if (matches.size() > 0 || matchesRC.size() > 0) {
+        identify_and_filter(matches, true, Plength, editDist, lis);
+        identify_and_filter(matchesRC, false, Plength, editDist, lis);
+        for (size_t i = 0; i < lis.size(); i++) lis[i].score = covered_bases(lis[i].matches);
+        std::sort(lis.begin(), lis.end(), [](const Lis& a, const Lis& b) { return a.score > b.score; });   // compIntervals :1114
+    }
+}
+
+// ------------------------------------------------------------------------------------------ chains
+// nextChain src/mapper.cpp:721-782
+static int next_chain(const std::vector<Match>& matches, std::list<size_t>& chain, size_t anchorPos, double errorPercent,
+                      std::vector<bool>& used, size_t qLength, int& coverage) {
+    int curEditDist = 0;
+    coverage = 0;
+    coverage += (int)matches[anchorPos].len;
+    chain.clear();
+    chain.push_back(anchorPos);
+    const Match& firstSeed = matches[anchorPos];
+    int64_t refstrLB = firstSeed.ref;
+    int64_t queryLB = firstSeed.query;
+    int64_t refstrRB = refstrLB + firstSeed.len - 1;
+    int64_t queryRB = queryLB + firstSeed.len - 1;
+    int memsIndex = (int)anchorPos + 1;
+    while (memsIndex < (int)matches.size()) {
+        const Match& match = matches[memsIndex];
+        int64_t qDist = match.query - (queryRB + 1);
+        int64_t refDist = match.ref - (refstrRB + 1);
+        int64_t qDistLong = match.query + match.len - queryLB;
+        int64_t refDistLong = match.ref + match.len - refstrLB;
+        if (qDist >= MAX_OVERLAP && refDist >= MAX_OVERLAP &&
+            std::llabs(qDist - refDist) <= (int64_t)(errorPercent * std::max(qDistLong, refDistLong))) {
+            chain.push_back(memsIndex);
+            curEditDist += (int)std::max((int64_t)1, (int64_t)std::llabs(qDist - refDist));
+            refstrLB = match.ref;
+            refstrRB = match.ref + match.len - 1;
+            queryLB = match.query;
+            queryRB = match.query + match.len - 1;
+            used[memsIndex] = true;
+            coverage += std::min(qDist, refDist) < 0 ? (int)(matches[memsIndex].len + std::min(qDist, refDist)) : (int)matches[memsIndex].len;
+        }
+        memsIndex++;
+    }
+    curEditDist += (int)(queryRB + 1) < (int)qLength ? 1 : 0;
+    memsIndex = (int)anchorPos - 1;
+    refstrLB = firstSeed.ref;
+    queryLB = firstSeed.query;
+    refstrRB = refstrLB + firstSeed.len - 1;
+    queryRB = queryLB + firstSeed.len - 1;
+    while (memsIndex >= 0) {
+        const Match& match = matches[memsIndex];
+        int64_t qDist = queryLB - (match.query + match.len);
+        int64_t refDist = refstrLB - (match.ref + match.len);
+        int64_t qDistLong = queryRB - (match.query) + 1;
+        int64_t refDistLong = refstrRB - (match.ref) + 1;
+        if (qDist >= MAX_OVERLAP && refDist >= MAX_OVERLAP &&
+            std::llabs(qDist - refDist) <= (int64_t)(errorPercent * std::max(qDistLong, refDistLong))) {
+            chain.push_front(memsIndex);
+            curEditDist += (int)std::max((int64_t)1, (int64_t)std::llabs(qDist - refDist));
+            refstrLB = match.ref;
+            refstrRB = match.ref + match.len - 1;
+            queryLB = match.query;
+            queryRB = match.query + match.len - 1;
+            used[memsIndex] = true;
+            coverage += std::min(qDist, refDist) < 0 ? (int)(matches[memsIndex].len + std::min(qDist, refDist)) : (int)matches[memsIndex].len;
+        }
+        memsIndex--;
+    }
+    curEditDist += queryLB > 0 ? 1 : 0;
+    return curEditDist;
+}
+
+// leftExtension src/mapper.cpp:784-824
+void Mapper::left_ext(const std::string& P, int& tmpQB, int64_t& tmpRB, int64_t chrStart, int& curScore, int bandSize, int editDist) {
+    if (tmpQB > 0 && tmpRB > chrStart) {
+        const char* S = idx_.S();
+        int64_t boundLeft = std::max(tmpRB - tmpQB - (editDist), chrStart);
+        int tLen = (int)(tmpRB - boundLeft);
+        std::vector<uint8_t> target((size_t)std::max(tLen, 0)), query((size_t)tmpQB);
+        for (int j = 0; j < tLen; ++j) target[j] = nt4((unsigned char)S[tmpRB - j - 1]);
+        for (int j = 0; j < tmpQB; ++j) query[j] = nt4((unsigned char)P[tmpQB - j - 1]);
+        alfa_extend_result r;
+        hot_.submit_extend(ExtendReq{alfa_dp_task{query.data(), target.data(), tmpQB, tLen, std::min(bandSize, tmpQB), curScore}, &r});
+        hot_.wait();
+        curScore = r.score;
+        if (opt_.global || r.gscore >= curScore + (opt_.mismatch - opt_.match) * 3) {
+            curScore = r.gscore;
+            tmpQB = 0;
+            tmpRB = tmpRB - r.gtle;
+        } else {
+            tmpQB = tmpQB - r.qle;
+            tmpRB = tmpRB - r.tle;
+        }
+    } else if (tmpQB > 0 && tmpRB == chrStart && opt_.global) {
+        curScore += opt_.openGap + opt_.extendGap * tmpQB;
+    }
+}
+
+// rightExtension src/mapper.cpp:826-867
+void Mapper::right_ext(const std::string& P, int& tmpQE, int64_t& tmpRE, int64_t chrEnd, int& curScore, int bandSize, int editDist) {
+    const int Plen = (int)P.length();
+    if (tmpQE < Plen - 1 && tmpRE < chrEnd) {
+        const char* S = idx_.S();
+        int64_t boundRight = std::min((int64_t)(tmpRE + (Plen - 1 - tmpQE) + editDist), chrEnd);
+        int tLen = (int)(boundRight - tmpRE);
+        int qLen = Plen - 1 - tmpQE;
+        std::vector<uint8_t> target((size_t)std::max(tLen, 0)), query((size_t)qLen);
+        for (int j = 0; j < tLen; ++j) target[j] = nt4((unsigned char)S[tmpRE + 1 + j]);
+        for (int j = 0; j < qLen; ++j) query[j] = nt4((unsigned char)P[tmpQE + 1 + j]);
+        alfa_extend_result r;
+        hot_.submit_extend(ExtendReq{alfa_dp_task{query.data(), target.data(), qLen, tLen, std::min(bandSize, qLen), curScore}, &r});
+        hot_.wait();
+        curScore = r.score;
+        if (opt_.global || r.gscore >= curScore + (opt_.mismatch - opt_.match) * 3) {
+            curScore = r.gscore;
+            tmpQE = Plen - 1;
+            tmpRE = tmpRE + r.gtle;
+        } else {
+            tmpQE = tmpQE + r.qle;
+            tmpRE = tmpRE + r.tle;
+        }
+    } else if (tmpQE < Plen - 1 && tmpRE == chrEnd && opt_.global) {
+        curScore += opt_.openGap + opt_.extendGap * (Plen - 1 - tmpQE);
+    }
+}
+
+// extendAlignmentChain src/mapper.cpp:869-1081
+int Mapper::extend_chain(const std::string& P, const std::vector<Match>& matches, int editDist, int minScore, int minCoverage,
+                         int64_t chrStart, int64_t chrEnd, Read& read, bool fw) {
+    const char* S = idx_.S();
+    int maxAlnScore = std::min(-1, minScore - 10);
+    std::list<size_t> chain;
+    std::vector<int64_t> seedOrder;
+    seedOrder.reserve(matches.size());
+    std::vector<bool> used(matches.size(), false);
+    for (size_t i = 0; i < matches.size(); i++) seedOrder.push_back((int64_t)matches[i].len << 32 | (int64_t)i);
+    std::sort(seedOrder.begin(), seedOrder.end());
+    std::vector<Bounds> alnBounds;
+    std::vector<int> alnScores;
+    std::vector<int64_t> alnBegins;
+    for (int i = (int)seedOrder.size() - 1; i >= 0; i--) {
+        size_t anchorPos = (uint32_t)seedOrder[i];
+        Match anchor = matches[anchorPos];
+        bool extend = !used[anchorPos];
+        size_t j = 0;
+        while (j < alnBounds.size() && extend) {
+            bool notContained = anchor.query < alnBounds[j].queryB || anchor.query + anchor.len >= alnBounds[j].queryE ||
+                                anchor.ref < alnBounds[j].refB || anchor.ref + anchor.len >= alnBounds[j].refE;
+            if (!notContained) {
+                int qDist = anchor.query - alnBounds[j].queryB;
+                int refDist = (int)(anchor.ref - alnBounds[j].refB);
+                int max_gapL = std::min(opt_.fixedBandSize, (int)((std::min(qDist, refDist) * opt_.match + opt_.openGap) / opt_.extendGap + 1.));
+                extend = std::max(qDist, refDist) >= max_gapL;
+                if (extend) {
+                    qDist = alnBounds[j].queryE - (anchor.query + anchor.len);
+                    refDist = (int)(alnBounds[j].refE - (anchor.ref + anchor.len));
+                    max_gapL = std::min(opt_.fixedBandSize, (int)((std::min(qDist, refDist) * opt_.match + opt_.openGap) / opt_.extendGap + 1.));
+                    extend = std::max(qDist, refDist) >= max_gapL;
+                }
+            }
+            j++;
+        }
+        if (!extend) continue;
+        int curScore = 0;
+        int minEdit = next_chain(matches, chain, anchorPos, opt_.errorPercent, used, P.length(), curScore);
+        if (!(minEdit <= editDist && (chain.size() > 1 || anchor.len >= minCoverage))) continue;
+        std::list<size_t>::const_iterator it = chain.begin(), itEnd = chain.end();
+        int bandSize = std::min(opt_.fixedBandSize, (int)(editDist - minEdit + 1));
+        anchor = matches[*it];
+        ++it;
+        int tmpQB = anchor.query;
+        int tmpQE = anchor.query + anchor.len - 1;
+        int64_t tmpRB = anchor.ref;
+        int64_t tmpRE = anchor.ref + anchor.len - 1;
+        // inside the chain: the closed-form gap cases, and one ksw_nw per remaining gap.  The nw calls of one chain
+        // are independent of each other (their scores are only summed), so they are submitted together.
+        struct Gap { std::vector<uint8_t> q, t; int32_t score; };
+        std::list<Gap> gaps;
+        while (it != itEnd) {
+            Match seed = matches[*it];
+            int64_t qDist = seed.query - tmpQE;
+            int64_t refDist = seed.ref - tmpRE;
+            if (qDist < 0 || refDist < 0) {
+                if (qDist >= refDist) qDist -= refDist;
+                else refDist -= qDist;
+            }
+            if (qDist <= 0) curScore += (int)(opt_.openGap + opt_.extendGap * refDist);
+            else if (refDist <= 0) curScore += (int)(opt_.openGap + opt_.extendGap * qDist);
+            else if (qDist == 1) curScore += (int)(opt_.openGap + opt_.extendGap * (refDist - 1));
+            else if (refDist == 1) curScore += (int)(opt_.openGap + opt_.extendGap * (qDist - 1));
+            else if (refDist == 2 && qDist == 2) curScore += opt_.mismatch;
+            else {
+                int tLen = (int)(seed.ref - tmpRE - 1);
+                int qLen = seed.query - tmpQE - 1;
+                gaps.emplace_back();
+                Gap& g = gaps.back();
+                g.t.resize((size_t)tLen);
+                g.q.resize((size_t)qLen);
+                for (int k = 0; k < tLen; ++k) g.t[k] = nt4((unsigned char)S[tmpRE + 1 + k]);
+                for (int k = 0; k < qLen; ++k) g.q[k] = nt4((unsigned char)P[tmpQE + 1 + k]);
+                int innerBand = std::min(opt_.fixedBandSize, (int)(editDist - minEdit + std::abs(qLen - tLen) + 3));
+                innerBand = std::max(innerBand, std::abs(qLen - tLen) + (int)(std::abs(qLen - tLen) * opt_.errorPercent));
+                hot_.submit_nw(NwReq{alfa_dp_task{g.q.data(), g.t.data(), qLen, tLen, innerBand, 0}, &g.score});
+            }
+            tmpRE = seed.ref + seed.len - 1;
+            tmpQE = seed.query + seed.len - 1;
+            ++it;
+        }
+        if (!gaps.empty()) {
+            hot_.wait();
+            for (const Gap& g : gaps) curScore += g.score;
+        }
+        if (tmpQB <= (int)(P.length() - 1) - tmpQE) {
+            left_ext(P, tmpQB, tmpRB, chrStart, curScore, bandSize, editDist - minEdit + 1);
+            right_ext(P, tmpQE, tmpRE, chrEnd, curScore, bandSize, editDist);
+        } else {
+            right_ext(P, tmpQE, tmpRE, chrEnd, curScore, bandSize, editDist);
+            left_ext(P, tmpQB, tmpRB, chrStart, curScore, bandSize, editDist - minEdit + 1);
+        }
+        maxAlnScore = std::max(maxAlnScore, curScore);
+        if (curScore >= minScore) {
+            bool equal = false;
+            for (size_t k = 0; k < alnScores.size(); k++)
+                if (alnScores[k] >= curScore && std::llabs(alnBegins[k] - tmpRB) < editDist) equal = true;
+            if (!equal) {
+                Alignment* a = new Alignment();
+                a->refB = tmpRB; a->refE = tmpRE; a->qB = tmpQB; a->qE = tmpQE;
+                a->alignmentScore = curScore;
+                if (!fw) a->flag |= 1u << 4;
+                a->refLength = (int)(tmpRE - tmpRB + 1);
+                for (size_t idx : chain) a->chain.push_back(matches[idx]);
+                read.alignments.push_back(a);
+                alnScores.push_back(curScore);
+                alnBegins.push_back(tmpRB);
+            }
+        }
+        alnBounds.push_back(Bounds{tmpRB, tmpRE, tmpQB, tmpQE});
+    }
+    return maxAlnScore >= minScore ? maxAlnScore : -1;
+}
+
+// processLisIntervals src/mapper.cpp:1118-1204 (hasUnique :1090-1112 with an ordered map instead of kbtree)
+void Mapper::process_lis(Read& read, const std::vector<Lis>& lis, int editDist, int maxAlnCount, int minCoverage, int minScore) {
+    size_t lisIndex = 0;
+    int trialF = 0, trialR = 0;
+    std::map<int64_t, int64_t> treeF, treeR;   // read position -> seed length
+    auto has_unique = [](const Lis& l, std::map<int64_t, int64_t>& tree) {
+        bool unique = false;
+        for (const Match& s : l.matches) {
+            const int64_t q = s.query, len = s.len;
+            if (!tree.empty()) {
+                auto ub = tree.upper_bound(q);                 // kb_interval: lower = largest key <= q
+                bool hasLower = ub != tree.begin();
+                auto lower = hasLower ? std::prev(ub) : tree.end();
+                if (!hasLower || lower->first + lower->second < q + len) {
+                    if (hasLower && lower->first == q) tree.erase(lower);
+                    tree[q] = len;
+                    unique = true;
+                }
+            } else {
+                tree[q] = len;
+                unique = true;
+            }
+        }
+        return unique;
+    };
+    int maxAlnScore = 0;
+    while ((int)read.alignments.size() < maxAlnCount && lisIndex < lis.size()) {
+        const Lis& cluster = lis[lisIndex];
+        bool unique = has_unique(cluster, cluster.fw ? treeF : treeR);
+        bool extend = unique;
+        int trial = cluster.fw ? trialF : trialR;
+        bool criterium = (trial < opt_.maxTrial || extend) && (cluster.matches.size() > 1 || cluster.score >= minCoverage);
+        if (criterium) {
+            int64_t chrStart, chrEnd;
+            idx_.chrom_bounds(cluster.matches[0].ref, chrStart, chrEnd);
+            int ret = extend_chain(cluster.fw ? read.sequence : read.rcSequence, cluster.matches, editDist, minScore, minCoverage, chrStart,
+                                   chrEnd, read, cluster.fw);
+            if (cluster.fw) trialF++; else trialR++;
+            if (ret >= 0 && (!opt_.maxTrialBest || maxAlnScore < ret)) {
+                if (cluster.fw) trialF = 0; else trialR = 0;
+            }
+            maxAlnScore = std::max(maxAlnScore, ret);
+        }
+        lisIndex++;
+    }
+}
+
+// unpairedMatch src/mapper.cpp:1269-1302
+void Mapper::unpaired_match(Read& read) {
+    std::vector<Lis> lis;
+    cand_regions(read, lis, opt_.errorPercent);
+    if (lis.empty()) return;
+    if (!read.alignments.empty()) {
+        // filterLISwithAlignments :1206-1218
+        for (size_t i = 0; i < read.alignments.size(); i++) {
+            Alignment* a = read.alignments[i];
+            for (auto it = lis.begin(); it != lis.end();) {
+                if (a->rc() != it->fw && a->refE >= it->refBegin && a->refB <= it->refEnd) it = lis.erase(it);
+                else ++it;
+            }
+        }
+    }
+    const int Plength = (int)read.sequence.length();
+    const int editDist = (int)(opt_.errorPercent * Plength) + 1;
+    int minScore = (int)(Plength * opt_.match + (opt_.mismatch - opt_.match) * editDist);
+    process_lis(read, lis, editDist, opt_.maxAlnCount, (int)(Plength * opt_.minCoverage), minScore);
+    if (read.alignments.empty() && opt_.rescue) {
+        minScore = std::max(0, (int)(Plength * opt_.match + (opt_.mismatch - opt_.match) * 0.2 * Plength));
+        int minCoverage = (int)(Plength * 0.01);
+        process_lis(read, lis, editDist, 20, minCoverage, minScore);
+    }
+    if (read.alignments.empty() && opt_.rescue) {
+        lis.clear();
+        cand_regions(read, lis, 2.0 * opt_.errorPercent);
+        if (!lis.empty()) {
+            minScore = std::max(0, (int)(Plength * opt_.match + (opt_.mismatch - opt_.match) * 0.2 * Plength));
+            int minCoverage = (int)(Plength * 0.01);
+            process_lis(read, lis, editDist, 20, minCoverage, minScore);
+        }
+    }
+}
+
+// alignment_t::setLocalPos src/mapper.h:104-112
+void Mapper::set_local_pos(Alignment& a) {
+    if (a.rname.empty() || a.rname == "*") {
+        int64_t seq, pos;
+        idx_.from_set(a.refB + 1, seq, pos);
+        a.pos = pos;
+        a.rname = idx_.descr(seq);
+    }
+}
+
+// read_t::postprocess src/mapper.cpp:322-379 with constructCIGAR :172-271 and fullDP :303-320.
+// All ksw_global calls of a read (one per chain gap + head + tail of every reported alignment) are independent:
+// they are submitted together and the strings are assembled afterwards in the reference's order.
+void Mapper::postprocess(Read& read, bool paired) {
+    if (read.alignments.empty()) return;
+    auto& al = read.alignments;
+    if (!paired) std::sort(al.begin(), al.end(), cmp_aln);
+    else std::sort(al.begin(), al.end(), cmp_aln_paired);
+    int maxDP = std::min((int)al.size(), opt_.alignmentCount);
+    if (opt_.fullDP) maxDP = std::min((int)al.size(), std::max(4, opt_.alignmentCount));
+    const char* S = idx_.S();
+    const int Plen = (int)read.sequence.length();
+    struct Piece { int kind; std::string lit; int dp; int editAdd; };   // kind 0: literal text (+edit), 1: DP result #dp
+    struct DpJob { std::vector<uint32_t> cigar; int32_t score; const uint8_t* q; const uint8_t* t; };
+    struct Plan { std::vector<uint8_t> target; std::vector<Piece> pieces; bool full = false; int fullJob = -1; };
+    std::vector<Plan> plans((size_t)maxDP);
+    std::list<DpJob> jobs;
+    std::vector<DpJob*> jobv;
+    auto add_job = [&](const uint8_t* q, int qLen, const uint8_t* t, int tLen, int band) {
+        jobs.emplace_back();
+        DpJob& j = jobs.back();
+        j.q = q; j.t = t;
+        hot_.submit_global(GlobalReq{alfa_dp_task{q, t, qLen, tLen, band, 0}, &j.score, &j.cigar});
+        jobv.push_back(&j);
+        return (int)jobv.size() - 1;
+    };
+    for (int j = 0; j < maxDP; j++) {
+        Alignment& a = *al[j];
+        set_local_pos(a);
+        const uint8_t* readP = a.rc() ? read.rcReadP.data() : read.readP.data();
+        Plan& pl = plans[j];
+        int qLen = a.qE - a.qB + 1;
+        int refLen = (int)(a.refE - a.refB + 1);
+        pl.target.resize((size_t)std::max(refLen, 0));
+        for (int i = 0; i < refLen; ++i) pl.target[i] = nt4((unsigned char)S[a.refB + i]);
+        const uint8_t* target = pl.target.data();
+        if (!a.chain.empty() && !opt_.fullDP) {
+            auto lit = [&](const std::string& s, int e) { pl.pieces.push_back(Piece{0, s, -1, e}); };
+            auto num = [](long v, char c) { std::ostringstream o; o << v << c; return o.str(); };
+            if (a.qB) lit(num(a.qB, 'S'), 0);
+            const std::vector<Match>& ch = a.chain;
+            if (ch[0].query > a.qB) {
+                qLen = ch[0].query - a.qB;
+                refLen = (int)(ch[0].ref - a.refB);
+                int band = band_estimate(opt_.fixedBandSize, qLen, refLen, opt_.match, opt_.openGap, opt_.extendGap, a.alignmentScore);
+                pl.pieces.push_back(Piece{1, "", add_job(readP + a.qB, qLen, target, refLen, band), 0});
+            }
+            lit(num(ch[0].len, '='), 0);
+            for (size_t i = 1; i < ch.size(); i++) {
+                int qDist = ch[i].query - (ch[i - 1].query + ch[i - 1].len - 1);
+                int refDist = (int)(ch[i].ref - (ch[i - 1].ref + ch[i - 1].len - 1));
+                if (qDist < 0 || refDist < 0) {
+                    if (qDist >= refDist) qDist -= refDist;
+                    else refDist -= qDist;
+                }
+                if (qDist <= 0) lit(num(refDist, 'D') + num(ch[i].len - 1 + qDist, '='), refDist);
+                else if (refDist <= 0) lit(num(qDist, 'I') + num(ch[i].len - 1 + refDist, '='), qDist);
+                else if (qDist == 1) lit(num(refDist - 1, 'D') + num(ch[i].len, '='), refDist - 1);
+                else if (refDist == 1) lit(num(qDist - 1, 'I') + num(ch[i].len, '='), qDist - 1);
+                else if (refDist == 2 && qDist == 2) lit(num(1, 'X') + num(ch[i].len, '='), 1);
+                else {
+                    qLen = ch[i].query - 1 - (ch[i - 1].query + ch[i - 1].len) + 1;
+                    refLen = (int)(ch[i].ref - 1 - (ch[i - 1].ref + ch[i - 1].len) + 1);
+                    int band = band_estimate(opt_.fixedBandSize, qLen, refLen, opt_.match, opt_.openGap, opt_.extendGap, a.alignmentScore);
+                    const uint8_t* q = readP + ch[i - 1].query + ch[i - 1].len;
+                    const uint8_t* t = target + (ch[i - 1].ref + ch[i - 1].len - a.refB);
+                    pl.pieces.push_back(Piece{1, "", add_job(q, qLen, t, refLen, band), 0});
+                    lit(num(ch[i].len, '='), 0);
+                }
+            }
+            const Match& last = ch.back();
+            if (last.query + last.len - 1 < a.qE) {
+                qLen = a.qE - (last.query + last.len) + 1;
+                refLen = (int)(a.refE - (last.ref + last.len) + 1);
+                int band = band_estimate(opt_.fixedBandSize, qLen, refLen, opt_.match, opt_.openGap, opt_.extendGap, a.alignmentScore);
+                pl.pieces.push_back(Piece{1, "", add_job(readP + last.query + last.len, qLen, target + (last.ref + last.len - a.refB), refLen, band), 0});
+            }
+            if (Plen - 1 - a.qE) lit(num(Plen - 1 - a.qE, 'S'), 0);
+        } else {
+            pl.full = true;
+            int band = band_estimate(opt_.fixedBandSize, qLen, refLen, opt_.match, opt_.openGap, opt_.extendGap, a.alignmentScore);
+            pl.fullJob = add_job(readP + a.qB, qLen, target, refLen, band);
+        }
+    }
+    if (!jobv.empty()) hot_.wait();
+    for (int j = 0; j < maxDP; j++) {
+        Alignment& a = *al[j];
+        Plan& pl = plans[j];
+        if (!pl.full) {
+            std::ostringstream sNM;
+            a.editDist = 0;
+            for (const Piece& p : pl.pieces) {
+                if (p.kind == 0) { sNM << p.lit; a.editDist += p.editAdd; }
+                else { DpJob& d = *jobv[p.dp]; a.editDist += cigar4(d.cigar, d.q, d.t, sNM, nullptr); }
+            }
+            a.NMtag = sNM.str();
+            a.cigar = cigar3_from4(a.NMtag);
+        } else {
+            // fullDP + setFieldsKsw src/mapper.cpp:120-170,303-320
+            DpJob& d = *jobv[pl.fullJob];
+            a.alignmentScore = d.score;
+            std::ostringstream sNM, sCig;
+            int beginGap = a.qB, endGap = Plen - 1 - a.qE;
+            if (beginGap) { sCig << beginGap << "S"; sNM << beginGap << "S"; }
+            a.editDist = cigar4(d.cigar, d.q, d.t, sNM, &sCig);
+            if (endGap) { sCig << endGap << "S"; sNM << endGap << "S"; }
+            a.cigar = sCig.str();
+            a.NMtag = sNM.str();
+        }
+    }
+    if (!paired) std::sort(al.begin(), al.end(), cmp_aln);
+    else std::sort(al.begin(), al.end(), cmp_aln_paired);
+    int maxScore = al[0]->alignmentScore + al[0]->mate.alignmentScore;
+    int secBest = al.size() > 1 ? al[1]->alignmentScore + al[1]->mate.alignmentScore : opt_.mismatch * (int)read.sequence.length();
+    int mapq = (secBest == (int)(opt_.mismatch * (int)read.sequence.length())) ? MAX_MAPQ
+                                                                                  : (int)(250 * ((double)(maxScore - secBest) / maxScore) + 0.499);
+    mapq = maxScore == secBest ? 0 : mapq;
+    mapq = std::min(std::max(0, mapq), MAX_MAPQ);
+    for (int j = 0; j < std::min((int)al.size(), opt_.alignmentCount); j++) {
+        if (al[j]->alignmentScore + al[j]->mate.alignmentScore == maxScore) al[j]->mapq = mapq;
+        else al[j]->flag |= 1u << 8;
+    }
+}
+
+void Mapper::map_unpaired(Read& read) {
+    read.init();
+    unpaired_match(read);
+    postprocess(read, false);
+}
+
+// ------------------------------------------------------------------------------------------ paired end, mode 1
+// isConcordant src/mapper.cpp:1311-1392
+bool Mapper::is_concordant(const Alignment& m1, const Alignment& m2) const {
+    bool firstLeft = true;
+    if (m1.rname != m2.rname) return false;
+    if (popt_.orientation == PAIR_FF) {
+        if (m1.rc() != m2.rc()) return false;
+        firstLeft = !m1.rc();
+    } else if (popt_.orientation == PAIR_FR) {
+        if (m1.rc() == m2.rc()) return false;
+        firstLeft = !m1.rc();
+    } else {
+        if (m1.rc() == m2.rc()) return false;
+        firstLeft = m1.rc();
+    }
+    if (firstLeft && m2.refE <= m1.refB) return false;
+    else if (!firstLeft && m1.refE <= m2.refB) return false;
+    int64_t begin = std::min(m1.refB, m2.refB);
+    int64_t end = std::max(m1.refE, m2.refE);
+    int64_t size = end - begin + 1;
+    if (size < popt_.minInsert || size > popt_.maxInsert) return false;
+    int64_t begin1 = m1.pos, end1 = begin1 + (int64_t)m1.refLength - 1;
+    int64_t begin2 = m2.pos, end2 = begin2 + (int64_t)m2.refLength - 1;
+    bool contain = (begin1 >= begin2 && end1 <= end2) || (begin2 >= begin1 && end2 <= end1);
+    if (contain && !popt_.contain) return false;
+    bool overlap = contain || (begin2 >= begin1 && begin2 <= end1) || (end2 >= begin1 && end2 <= end1);
+    if (!popt_.overlap && overlap) return false;
+    if ((firstLeft && (begin2 < begin1)) || (!firstLeft && (begin1 < begin2))) {
+        if (!overlap) return false;
+        else if (!popt_.dovetail) return false;
+    }
+    return true;
+}
+
+// alignment_t::setMate src/mapper.cpp:273-289
+static void set_mate(Alignment& a, const Alignment& o, bool concordant, bool upstream) {
+    a.mate.flag |= 1u | (1u << 1);
+    if (o.rc()) a.mate.flag |= 1u << 5; else a.mate.flag &= ~(1u << 5);
+    if (upstream) { a.mate.flag |= 1u << 6; a.mate.flag &= ~(1u << 7); }
+    else { a.mate.flag &= ~(1u << 6); a.mate.flag |= 1u << 7; }
+    a.mate.concordant = concordant;
+    a.mate.pnext = o.pos;
+    a.mate.pnextGlob = o.refB;
+    a.mate.tLength = (int)(std::max(a.refE, o.refE) - std::min(a.refB, o.refB) + 1);
+    int64_t firstPos = a.rc() ? a.refE : a.refB;
+    int64_t secondPos = o.rc() ? o.refE : o.refB;
+    if (firstPos > secondPos) a.mate.tLength *= -1;
+    a.mate.rnext = a.rname == o.rname ? "=" : o.rname;
+    if (concordant) a.mate.alignmentScore = o.alignmentScore;
+}
+
+// unpairedCopy :1394-1408
+static Alignment* unpaired_copy(const Alignment* a) {
+    Alignment* n = new Alignment();
+    n->refB = a->refB; n->refE = a->refE; n->qB = a->qB; n->qE = a->qE; n->pos = a->pos; n->rname = a->rname;
+    n->refLength = a->refLength; n->alignmentScore = a->alignmentScore;
+    if (a->rc()) n->flag |= 1u << 4;
+    n->chain = a->chain;
+    return n;
+}
+
+// setPaired (both overloads) src/mapper.cpp:1410-1437
+void Mapper::set_paired(Read& m1, Read& m2, int i, int j, bool concordant) {
+    set_local_pos(*m1.alignments[i]);
+    set_local_pos(*m2.alignments[j]);
+    int i1 = i, i2 = j;
+    if (m1.alignments[i1]->paired()) { m1.alignments.push_back(unpaired_copy(m1.alignments[i1])); i1 = (int)m1.alignments.size() - 1; }
+    if (m2.alignments[i2]->paired()) { m2.alignments.push_back(unpaired_copy(m2.alignments[i2])); i2 = (int)m2.alignments.size() - 1; }
+    m1.pairedAlignmentCount++;
+    m2.pairedAlignmentCount++;
+    Alignment& a = *m1.alignments[i1];
+    Alignment& b = *m2.alignments[i2];
+    a.flag |= 1u; b.flag |= 1u;
+    set_mate(a, b, concordant, true);
+    set_mate(b, a, concordant, false);
+}
+
+// pairedMatch1 src/mapper.cpp:1640-1682 (without --paired-rescue, which needs ksw_align: SURVEY 8f next #1)
+void Mapper::paired_match1(Read& m1, Read& m2) {
+    unpaired_match(m1);
+    unpaired_match(m2);
+    const int alnCount1 = (int)m1.alignments.size(), alnCount2 = (int)m2.alignments.size();
+    int alnCount = 0;
+    const int maxPaired = opt_.alignmentCount + 1;
+    struct Info { bool first; int pos; int score; };
+    std::vector<Info> order;
+    order.reserve((size_t)(alnCount1 + alnCount2));
+    for (int i = 0; i < alnCount1; i++) order.push_back(Info{true, i, m1.alignments[i]->alignmentScore});
+    for (int i = 0; i < alnCount2; i++) order.push_back(Info{false, i, m2.alignments[i]->alignmentScore});
+    std::sort(order.begin(), order.end(), [](const Info& a, const Info& b) { return a.score > b.score; });   // compAlnScorePaired :1520
+    if (alnCount1 > 0 && alnCount2 > 0) {
+        // pairAlignmentsOrdered :1608-1637
+        size_t i = 0;
+        while (i < order.size() && alnCount < maxPaired) {
+            size_t j = i + 1;
+            bool paired = order[i].first ? m1.alignments[order[i].pos]->paired() : m2.alignments[order[i].pos]->paired();
+            if (!paired) {
+                while (j < order.size() && alnCount < maxPaired) {
+                    if (order[i].first != order[j].first) {
+                        int i1 = order[i].first ? order[i].pos : order[j].pos;
+                        int i2 = order[i].first ? order[j].pos : order[i].pos;
+                        Alignment* a1 = m1.alignments[i1];
+                        set_local_pos(*a1);
+                        Alignment* a2 = m2.alignments[i2];
+                        set_local_pos(*a2);
+                        if (is_concordant(*a1, *a2)) { set_paired(m1, m2, i1, i2, true); alnCount++; }
+                    }
+                    j++;
+                }
+            }
+            i++;
+        }
+    }
+    if (popt_.discordant && alnCount < maxPaired) {
+        // calculateDiscordantAlignments :1439-1462
+        if (!m1.alignments.empty() && !m2.alignments.empty()) {
+            std::sort(m1.alignments.begin(), m1.alignments.end(), cmp_aln);
+            std::sort(m2.alignments.begin(), m2.alignments.end(), cmp_aln);
+            int maxFirst = m1.alignments[0]->alignmentScore, maxSecond = m2.alignments[0]->alignmentScore;
+            size_t n1 = m1.alignments.size(), n2 = m2.alignments.size();
+            size_t i = 0;
+            while (i < n1 && m1.alignments[i]->alignmentScore == maxFirst) {
+                if (!m1.alignments[i]->concordant()) {
+                    size_t j = i;
+                    while (j < n2 && m2.alignments[j]->alignmentScore == maxSecond) {
+                        if (!m2.alignments[j]->concordant()) set_paired(m1, m2, (int)i, (int)j, false);
+                        j++;
+                    }
+                }
+                i++;
+            }
+        }
+    }
+}
+
+void Mapper::map_paired(Read& m1, Read& m2) {
+    m1.init();
+    m2.init();
+    paired_match1(m1, m2);
+    postprocess(m1, true);
+    postprocess(m2, true);
+}
+
+}  // namespace alfa

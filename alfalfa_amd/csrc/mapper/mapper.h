@@ -1,0 +1,134 @@
+// mapper.h -- host-side caller of the hot path: candidate regions, chaining, extension bookkeeping,
+// CIGAR/MAPQ and SAM records, with the reference's semantics (src/mapper.cpp, src/mapper.h, src/options.cpp).
+// This is the *caller* of libalfa_hot, not the accelerated path: it decides which seeds/DP calls are issued
+// and turns their results into SAM.  Written from scratch; every function cites the reference lines whose
+// behaviour it reproduces.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../../include/alfa_index.h"
+#include "hot_sched.h"
+
+namespace alfa {
+
+enum SeedType { SEED_SMAM = 0, SEED_MEM = 1, SEED_SMEM = 2, SEED_SMEMP = 3 };
+enum Orientation { PAIR_FR, PAIR_RF, PAIR_FF };
+
+struct AlignOpt {                 // align_opt, defaults of mapOptions_t::initOptions (src/options.cpp:43-92)
+    int match = 1, mismatch = -4, openGap = -6, extendGap = -1;
+    int8_t mat[25];
+    bool global = true;
+    double errorPercent = 0.08;
+    int minMemLength = 40;
+    bool fixedMinLength = false;
+    int alignmentCount = 1;
+    int maxTrial = 10, minTrial = 5000;
+    bool maxTrialBest = true;
+    bool alwaysUnique = true;
+    double minCoverage = 0.25;
+    bool rescue = true, noSparseQ = false, fullDP = false;
+    int maxSeedCandidates = 10000, maxSmemMemStart = 10, maxRegionMems = 20, minMemRegLength = 50;
+    bool noFW = false, noRC = false;
+    int memType = SEED_SMAM;
+    int fixedBandSize = 100;
+    int maxAlnCount = 5000;
+    void fill_m();                // align_opt::fill_m src/options.cpp:33-41
+};
+
+struct PairedOpt {
+    int minInsert = 0, maxInsert = 1000;
+    bool mixed = true, discordant = true, dovetail = false, contain = true, overlap = true;
+    int mode = 1;
+    bool pairedRescue = false;
+    Orientation orientation = PAIR_FR;
+};
+
+struct MateInfo {                 // mate_t src/mapper.h:67-78
+    unsigned flag = 0;
+    std::string rnext = "*";
+    int64_t pnext = 0, pnextGlob = 0;
+    int tLength = 0;
+    bool concordant = false;
+    int alignmentScore = 0;
+};
+
+struct Alignment {                // alignment_t src/mapper.h:80-124
+    int64_t refB = 0, refE = 0;
+    int qB = 0, qE = 0;
+    int64_t pos = 0;
+    std::string cigar = "*";
+    unsigned flag = 0;
+    std::string rname = "*";
+    int mapq = 0, editDist = 0, alignmentScore = 0;
+    std::string NMtag = "*";
+    int refLength = 0;
+    MateInfo mate;
+    std::vector<Match> chain;
+    bool paired() const { return flag & 1u; }
+    bool concordant() const { return paired() && mate.concordant; }
+    bool rc() const { return (flag >> 4) & 1u; }
+};
+
+struct Read {                     // read_t src/mapper.h:126-219
+    std::string qname, sequence, qual = "*", rcSequence, rQual;
+    std::vector<uint8_t> readP, rcReadP;
+    std::vector<Alignment*> alignments;
+    int pairedAlignmentCount = 0;
+    ~Read();
+    Read() = default;
+    Read(const Read&) = delete;
+    Read& operator=(const Read&) = delete;
+    Read(Read&& o) noexcept;
+    void init();                  // read_t::init src/mapper.h:155-166
+    std::string emptyAlignment(bool paired, bool mateFailed, bool upstream) const;
+    std::string printUnpaired(int i) const;
+    std::string printPaired(int i, bool firstMate);
+};
+
+struct RefIndex {                 // the parts of `sparseSA` the mapper itself touches
+    const alfa_host_index* h = nullptr;
+    const alfa_index_view* v = nullptr;
+    const char* S() const { return (const char*)v->S; }
+    int64_t K() const { return v->K; }
+    void from_set(int64_t hit, int64_t& seq, int64_t& seqpos) const { alfa_host_index_from_set(h, hit, &seq, &seqpos); }
+    void chrom_bounds(int64_t hit, int64_t& cs, int64_t& ce) const { alfa_host_index_chrom_bounds(h, hit, &cs, &ce); }
+    const char* descr(int64_t i) const { return alfa_host_index_descr(h, (int)i); }
+};
+
+class Mapper {
+   public:
+    Mapper(const RefIndex& idx, const AlignOpt& a, const PairedOpt& p, HotSched& hot) : idx_(idx), opt_(a), popt_(p), hot_(hot) {}
+    // map_unpaired: unpairedMatch + postprocess (src/main.cpp:87-104)
+    void map_unpaired(Read& read);
+    // map_paired: pairedMatch (mode 1) + postprocess of both mates (src/main.cpp:179-195)
+    void map_paired(Read& m1, Read& m2);
+
+   private:
+    struct Lis {                  // lis_t src/mapper.h:42-65
+        int score = 0; bool fw = true; int64_t refBegin = 0, refEnd = 0; std::vector<Match> matches;
+    };
+    void unpaired_match(Read& read);
+    void seeds_both_strands(const std::string& P, const std::string& Prc, int min_len, std::vector<Match>& fw, std::vector<Match>& rc);
+    void identify_and_filter(std::vector<Match>& matches, bool fw, int qLength, int editDist, std::vector<Lis>& lis);
+    void cand_regions(const Read& read, std::vector<Lis>& lis, double errorPercent);
+    void process_lis(Read& read, const std::vector<Lis>& lis, int editDist, int maxAlnCount, int minCoverage, int minScore);
+    int extend_chain(const std::string& P, const std::vector<Match>& matches, int editDist, int minScore, int minCoverage,
+                     int64_t chrStart, int64_t chrEnd, Read& read, bool fw);
+    void left_ext(const std::string& P, int& tmpQB, int64_t& tmpRB, int64_t chrStart, int& curScore, int bandSize, int editDist);
+    void right_ext(const std::string& P, int& tmpQE, int64_t& tmpRE, int64_t chrEnd, int& curScore, int bandSize, int editDist);
+    void postprocess(Read& read, bool paired);
+    void set_local_pos(Alignment& a);
+    void paired_match1(Read& m1, Read& m2);
+    void set_paired(Read& m1, Read& m2, int i, int j, bool concordant);
+    bool is_concordant(const Alignment& a, const Alignment& b) const;
+    const RefIndex& idx_;
+    const AlignOpt& opt_;
+    const PairedOpt& popt_;
+    HotSched& hot_;
+};
+
+std::string sam_header(const RefIndex& idx, int argc, char** argv);
+
+}  // namespace alfa

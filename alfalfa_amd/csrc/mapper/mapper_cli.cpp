@@ -1,0 +1,346 @@
+// mapper_cli.cpp -- command line driver: `alfalfa_amd index ...` / `alfalfa_amd align ...`
+// Same commands, flags and defaults as the reference (src/options.h:186-265, src/options.cpp:43-92,187-407) and
+// the same batch / ordered-output structure as its driver (src/main.cpp:64-149,151-264), with the per-read
+// kt_for loop replaced by worker threads that each run a fiber scheduler (hot_sched.h) feeding libalfa_hot.
+#include "mapper_cli.h"
+
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "../seqio.h"
+
+namespace alfa {
+
+namespace {
+
+struct Options {
+    std::string command;
+    int K = 12, threads = 1;
+    std::string unpairedQ, pair1, pair2, ref_fasta, index_prefix, indexLocation, outputName;
+    bool saveIndex = false, hasChild = true, hasSuflink = false, hasKmer = true;
+    AlignOpt aln;
+    PairedOpt paired;
+    int verbose = 0;
+    // extensions of this implementation
+    int fibers = 4096, gpus = 1, device = 0;
+    bool stats = false;
+};
+
+int seed_type(const std::string& t) {       // parseSeedType src/options.cpp:155-172 (CLI names are shifted)
+    if (t == "MEM") return SEED_MEM;
+    if (t == "SMEM" || t == "SMAM") return SEED_SMAM;
+    if (t == "PSMEM") return SEED_SMEM;
+    if (t == "MAM" || t == "MUM") { fprintf(stderr, "ERROR: seed type %s is not supported\n", t.c_str()); exit(1); }
+    fprintf(stderr, "WARNING: unrecognized seed type. SMEMs are used instead.\n");
+    return SEED_SMAM;
+}
+
+bool parse(int argc, char** argv, Options& o) {
+    if (argc < 2) return false;
+    o.command = argv[1];
+    if (o.command != "index" && o.command != "align") return false;
+    auto need = [&](int& i) -> const char* {
+        if (i + 1 >= argc) { fprintf(stderr, "ERROR: option %s needs an argument\n", argv[i]); exit(1); }
+        return argv[++i];
+    };
+    for (int i = 2; i < argc; ++i) {
+        std::string a = argv[i];
+        auto is = [&](const char* s, const char* l) { return (s && a == std::string("-") + s) || (l && a == std::string("--") + l); };
+        if (is("r", "reference")) o.ref_fasta = need(i);
+        else if (is("s", "sparseness")) o.K = atoi(need(i));
+        else if (is("p", "prefix")) o.index_prefix = need(i);
+        else if (is(nullptr, "no-child")) o.hasChild = false;
+        else if (is(nullptr, "suflink")) o.hasSuflink = true;
+        else if (is(nullptr, "no-kmer")) o.hasKmer = false;
+        else if (is("i", "index")) o.indexLocation = need(i);
+        else if (is(nullptr, "save")) o.saveIndex = true;
+        else if (is("0", "single")) o.unpairedQ = need(i);
+        else if (is("1", "mates1")) o.pair1 = need(i);
+        else if (is("2", "mates2")) o.pair2 = need(i);
+        else if (is("o", "output")) o.outputName = need(i);
+        else if (is("a", "alignments")) o.aln.alignmentCount = atoi(need(i));
+        else if (is(nullptr, "no-forward")) o.aln.noFW = true;
+        else if (is(nullptr, "no-reverse")) o.aln.noRC = true;
+        else if (is("e", "edit-distance")) o.aln.errorPercent = atof(need(i)) + 0.01;     // src/options.cpp:296
+        else if (is(nullptr, "no-rescue")) o.aln.rescue = false;
+        else if (is("t", "threads")) o.threads = atoi(need(i));
+        else if (is(nullptr, "seed")) o.aln.memType = seed_type(need(i));
+        else if (is("l", "min-length")) { o.aln.minMemLength = atoi(need(i)); o.aln.fixedMinLength = true; }
+        else if (is("m", "max-seeds")) o.aln.maxSeedCandidates = atoi(need(i));
+        else if (is(nullptr, "max-smems")) o.aln.maxSmemMemStart = atoi(need(i));
+        else if (is(nullptr, "max-mems")) o.aln.maxRegionMems = atoi(need(i));
+        else if (is(nullptr, "min-mem-length")) o.aln.minMemRegLength = atoi(need(i));
+        else if (is(nullptr, "no-sparseness")) o.aln.noSparseQ = true;
+        else if (is("f", "max-failures")) o.aln.maxTrial = atoi(need(i));
+        else if (is(nullptr, "reset-failures")) o.aln.maxTrialBest = false;
+        else if (is(nullptr, "max-alignments")) o.aln.minTrial = atoi(need(i));              // writes minTrial (:323)
+        else if (is("c", "min-coverage")) o.aln.minCoverage = atof(need(i));
+        else if (is(nullptr, "skip-unique")) { o.aln.alwaysUnique = false; need(i); }        // declared Arg::Required
+        else if (is(nullptr, "full-dp")) o.aln.fullDP = true;
+        else if (is(nullptr, "local")) o.aln.global = false;
+        else if (is("b", "bandwidth")) o.aln.fixedBandSize = atoi(need(i));
+        else if (is("M", "match")) o.aln.match = atoi(need(i));
+        else if (is("U", "mismatch")) o.aln.mismatch = atoi(need(i));
+        else if (is("O", "gap-open")) o.aln.openGap = atoi(need(i));
+        else if (is("E", "gap-extend")) o.aln.extendGap = atoi(need(i));
+        else if (is("I", "min-insert")) o.paired.minInsert = atoi(need(i));
+        else if (is("X", "max-insert")) o.paired.maxInsert = atoi(need(i));
+        else if (is(nullptr, "orientation")) {
+            std::string t = need(i);
+            o.paired.orientation = t == "rf" ? PAIR_RF : t == "ff" ? PAIR_FF : PAIR_FR;
+        }
+        else if (is(nullptr, "no-mixed")) o.paired.mixed = false;
+        else if (is(nullptr, "no-discordant")) o.paired.discordant = false;
+        else if (is(nullptr, "dovetail")) o.paired.dovetail = true;
+        else if (is(nullptr, "no-contain")) o.paired.contain = false;
+        else if (is(nullptr, "no-overlap")) o.paired.overlap = false;
+        else if (is(nullptr, "paired-mode")) o.paired.mode = atoi(need(i));
+        else if (is(nullptr, "paired-rescue")) o.paired.pairedRescue = true;
+        else if (is("v", "verbose")) o.verbose = atoi(need(i));
+        else if (is(nullptr, "fibers")) o.fibers = atoi(need(i));
+        else if (is(nullptr, "gpus")) o.gpus = atoi(need(i));
+        else if (is(nullptr, "device")) o.device = atoi(need(i));
+        else if (is(nullptr, "stats")) o.stats = true;
+        else { fprintf(stderr, "ERROR: unknown option %s\n", a.c_str()); exit(1); }
+    }
+    if (o.command == "index") {
+        if (o.ref_fasta.empty()) { fprintf(stderr, "ERROR: no reference file given.\n"); exit(1); }
+        if (o.index_prefix.empty()) o.index_prefix = o.ref_fasta;
+        return true;
+    }
+    if (o.ref_fasta.empty() && o.indexLocation.empty()) { fprintf(stderr, "ERROR: no reference or index name given.\n"); exit(1); }
+    if (o.indexLocation.empty() && o.index_prefix.empty()) o.index_prefix = o.ref_fasta;
+    if (o.unpairedQ.empty() && (o.pair1.empty() || o.pair2.empty())) {
+        fprintf(stderr, "ERROR: ALFALFA requires query files. Specify query files with -0 or -1,-2 options.\n");
+        exit(1);
+    }
+    if (o.outputName.empty()) o.outputName = o.ref_fasta + ".sam";
+    if (o.aln.errorPercent < 0.0 || o.aln.errorPercent > 1.0) { fprintf(stderr, "ERROR: uncorrect value for edit distance.\n"); exit(1); }
+    if (o.aln.minCoverage < 0.0 || o.aln.minCoverage > 1.0) { fprintf(stderr, "ERROR: uncorrect value for minimum coverage.\n"); exit(1); }
+    if (o.paired.minInsert > o.paired.maxInsert) { fprintf(stderr, "ERROR: minimum insert size is larger than maximum insert size\n"); exit(1); }
+    if (o.paired.mode != 1 || o.paired.pairedRescue) {
+        fprintf(stderr, "ERROR: only --paired-mode 1 without --paired-rescue is implemented (the others need ksw_align; SURVEY 8f)\n");
+        exit(1);
+    }
+    o.aln.maxAlnCount = std::max(o.aln.alignmentCount, o.aln.minTrial);      // src/options.cpp:400
+    o.aln.fill_m();
+    return true;
+}
+
+// fastqInputReader::nextRead src/fasta.cpp:135-159 + the '/1' '/2' stripping of src/main.cpp:91-92
+bool next_read(SeqReader& rd, Read& r) {
+    SeqRecord rec;
+    if (rd.next(rec) < 0) return false;
+    r.qname = rec.name;
+    r.sequence = rec.seq;
+    for (auto& c : r.sequence) c = (char)std::tolower((unsigned char)c);
+    if (!rec.qual.empty()) r.qual = rec.qual;
+    if (r.qname.length() > 2 && r.qname[r.qname.length() - 2] == '/') r.qname.erase(r.qname.length() - 2);
+    return true;
+}
+
+// persistent worker pool: every batch is split into contiguous slices, one per worker
+class Pool {
+   public:
+    Pool(int n, std::function<void(int)> init) : n_(n) {
+        for (int t = 0; t < n; ++t) th_.emplace_back([this, t, init] { init(t); loop(t); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void run(const std::function<void(int)>& fn) {
+        std::unique_lock<std::mutex> g(mu_);
+        fn_ = &fn; pending_ = n_; gen_++;
+        cv_.notify_all();
+        done_.wait(g, [this] { return pending_ == 0; });
+    }
+   private:
+    void loop(int t) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)>* fn;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                fn = fn_;
+            }
+            (*fn)(t);
+            { std::lock_guard<std::mutex> g(mu_); if (--pending_ == 0) done_.notify_all(); }
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+}  // namespace
+
+int mapper_main(int argc, char** argv, const HotBinding& bind) {
+    Options o;
+    if (!parse(argc, argv, o)) {
+        fprintf(stderr, "usage: %s index -r ref.fa [-s K] [-p prefix] [--no-child] [--suflink] [--no-kmer]\n"
+                        "       %s align (-r ref.fa | -i index) (-0 reads.fq | -1 m1.fq -2 m2.fq) [-o out.sam] [reference options]\n",
+                argv[0], argv[0]);
+        return 1;
+    }
+    alfa_host_index* hidx = nullptr;
+    if (o.command == "index") {
+        if (alfa_host_index_build_fasta(o.ref_fasta.c_str(), o.K, o.hasSuflink, o.hasChild, o.hasKmer, &hidx)) {
+            fprintf(stderr, "ERROR: %s\n", alfa_last_error());
+            return 1;
+        }
+        // the reference only saves with --save (src/main.cpp:321); an index command that saves nothing is useless, so we
+        // always save here -- the files are byte-identical to the reference's
+        if (alfa_host_index_save(hidx, o.index_prefix.c_str())) { fprintf(stderr, "ERROR: %s\n", alfa_last_error()); return 1; }
+        alfa_host_index_free(hidx);
+        return 0;
+    }
+    if (o.indexLocation.empty() || alfa_host_index_load(o.indexLocation.c_str(), &hidx) != 0) {
+        if (o.ref_fasta.empty()) { fprintf(stderr, "ERROR: index %s could not be loaded and no reference given\n", o.indexLocation.c_str()); return 1; }
+        if (alfa_host_index_build_fasta(o.ref_fasta.c_str(), o.K, o.hasSuflink, o.hasChild, o.hasKmer, &hidx)) {
+            fprintf(stderr, "ERROR: %s\n", alfa_last_error());
+            return 1;
+        }
+        if (o.saveIndex) alfa_host_index_save(hidx, o.index_prefix.c_str());
+    }
+    RefIndex idx;
+    idx.h = hidx;
+    idx.v = alfa_host_index_view(hidx);
+
+    alfa_dp_params prm;
+    memset(&prm, 0, sizeof(prm));
+    prm.m = 5;
+    memcpy(prm.mat, o.aln.mat, 25);
+    prm.gapo = -o.aln.openGap; prm.gape = -o.aln.extendGap; prm.zdrop = 100;   // call sites src/mapper.cpp:787-804
+
+    const int T = std::max(1, o.threads);
+    const int G = std::max(1, o.gpus);
+    std::vector<HotOps> ops((size_t)G);
+    for (int g = 0; g < G; ++g)
+        if (bind.make_ops(o.device + g, hidx, &ops[g])) { fprintf(stderr, "ERROR: cannot set up the hot path on device %d: %s\n", o.device + g, bind.last_error()); return 1; }
+
+    FILE* out = fopen(o.outputName.c_str(), "w");
+    if (!out) { fprintf(stderr, "ERROR: cannot write %s\n", o.outputName.c_str()); return 1; }
+    fputs(sam_header(idx, argc, argv).c_str(), out);
+
+    std::vector<std::unique_ptr<HotSched>> scheds((size_t)T);
+    std::vector<std::unique_ptr<Mapper>> mappers((size_t)T);
+    Pool pool(T, [&](int t) {
+        bind.bind_thread(o.device + t % G);
+        scheds[t].reset(new HotSched(ops[t % G], prm));
+        mappers[t].reset(new Mapper(idx, o.aln, o.paired, *scheds[t]));
+    });
+    const int64_t bpCount = (int64_t)T * 10000000;   // BUFFER_SIZE src/main.cpp:54,116
+
+    long total = 0, mapped1 = 0, mapped2 = 0, printed1 = 0, printed2 = 0;
+    if (!o.unpairedQ.empty()) {
+        SeqReader rd;
+        if (!rd.open(o.unpairedQ.c_str())) { fprintf(stderr, "ERROR: file %s could not be read.", o.unpairedQ.c_str()); return 1; }
+        for (;;) {
+            std::vector<Read> reads;
+            int64_t cur = 0;
+            while (cur < bpCount) {
+                Read r;
+                if (!next_read(rd, r)) break;
+                cur += (int64_t)r.sequence.length();
+                reads.push_back(std::move(r));
+            }
+            if (reads.empty()) break;
+            const int n = (int)reads.size();
+            total += n;
+            pool.run([&](int t) {
+                const int lo = (int)((int64_t)n * t / T), hi = (int)((int64_t)n * (t + 1) / T);
+                Mapper& mp = *mappers[t];
+                scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.map_unpaired(reads[lo + i]); });
+            });
+            for (int i = 0; i < n; i++) {
+                if (reads[i].alignments.empty()) fputs(reads[i].emptyAlignment(false, false, true).c_str(), out);
+                else {
+                    mapped1++;
+                    int k = std::min((int)reads[i].alignments.size(), o.aln.alignmentCount);
+                    printed1 += k;
+                    for (int j = 0; j < k; j++) fputs(reads[i].printUnpaired(j).c_str(), out);
+                }
+            }
+        }
+        printf("sequences read: %ld\nsequences mapped: %ld\nalignments printed: %ld\n", total, mapped1, printed1);
+    }
+    if (!o.pair1.empty() && !o.pair2.empty()) {
+        SeqReader r1, r2;
+        if (!r1.open(o.pair1.c_str()) || !r2.open(o.pair2.c_str())) { fprintf(stderr, "ERROR: mate files could not be read."); return 1; }
+        total = mapped1 = printed1 = 0;
+        for (;;) {
+            std::vector<Read> m1, m2;
+            int64_t cur = 0;
+            while (cur < bpCount) {
+                Read a, b;
+                bool ok1 = next_read(r1, a);
+                bool ok2 = next_read(r2, b);     // the reference keeps only the second status (src/main.cpp:157-158)
+                (void)ok1;
+                if (!ok2) break;
+                cur += (int64_t)a.sequence.length();
+                m1.push_back(std::move(a));
+                m2.push_back(std::move(b));
+            }
+            if (m1.empty()) break;
+            const int n = (int)m1.size();
+            total += n;
+            pool.run([&](int t) {
+                const int lo = (int)((int64_t)n * t / T), hi = (int)((int64_t)n * (t + 1) / T);
+                Mapper& mp = *mappers[t];
+                scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.map_paired(m1[lo + i], m2[lo + i]); });
+            });
+            for (int i = 0; i < n; i++) {
+                if (m1[i].alignments.empty()) fputs(m1[i].emptyAlignment(true, m2[i].alignments.empty(), true).c_str(), out);
+                else {
+                    mapped1++;
+                    int k = o.paired.mixed ? std::min((int)m1[i].alignments.size(), o.aln.alignmentCount)
+                                           : std::min(m1[i].pairedAlignmentCount, o.aln.alignmentCount);
+                    printed1 += k;
+                    for (int j = 0; j < k; j++) fputs(m1[i].printPaired(j, true).c_str(), out);
+                }
+                if (m2[i].alignments.empty()) fputs(m2[i].emptyAlignment(true, m1[i].alignments.empty(), false).c_str(), out);
+                else {
+                    mapped2++;
+                    int k = o.paired.mixed ? std::min((int)m2[i].alignments.size(), o.aln.alignmentCount)
+                                           : std::min(m2[i].pairedAlignmentCount, o.aln.alignmentCount);
+                    printed2 += k;
+                    for (int j = 0; j < k; j++) fputs(m2[i].printPaired(j, false).c_str(), out);
+                }
+            }
+        }
+        printf("sequences read: %ld\nsequences mapped (mate1): %ld\nsequences mapped (mate2): %ld\n"
+               "alignments printed (mate1): %ld\nalignments printed (mate2): %ld\n", total, mapped1, mapped2, printed1, printed2);
+    }
+    fclose(out);
+    if (o.stats) {
+        SchedStats s;
+        for (auto& sc : scheds) {
+            const SchedStats& x = sc->stats();
+            s.rounds += x.rounds; s.seed_calls += x.seed_calls; s.seed_queries += x.seed_queries; s.ext_calls += x.ext_calls;
+            s.ext_tasks += x.ext_tasks; s.nw_calls += x.nw_calls; s.nw_tasks += x.nw_tasks; s.glob_calls += x.glob_calls;
+            s.glob_tasks += x.glob_tasks; s.hot_seconds += x.hot_seconds;
+        }
+        fprintf(stderr, "#STATS rounds %ld seed_calls %ld seed_queries %ld extend %ld/%ld nw %ld/%ld global %ld/%ld hot_seconds %.3f\n",
+                (long)s.rounds, (long)s.seed_calls, (long)s.seed_queries, (long)s.ext_calls, (long)s.ext_tasks, (long)s.nw_calls,
+                (long)s.nw_tasks, (long)s.glob_calls, (long)s.glob_tasks, s.hot_seconds);
+    }
+    for (int g = 0; g < G; ++g) bind.release_ops(&ops[g]);
+    alfa_host_index_free(hidx);
+    return 0;
+}
+
+}  // namespace alfa
