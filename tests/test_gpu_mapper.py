@@ -1,0 +1,62 @@
+"""GPU parity, end to end: the product command line tool (host mapper + libalfa_hot HIP kernels) must write the
+compiled reference's SAM records byte for byte (BASELINE configs[0] and [1] + variants)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import mapper_util as M
+import golden_util as G
+import seqgen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", M.SMAM_CONFIGS)
+def test_gpu_mapper_matches_reference_sam(gpu, name):
+    body = M.run_config(M.GPU_EXE, name, ["-t", "2"])
+    assert M.md5(body) == M.golden_md5(name)
+
+
+def test_gpu_mapper_unsupported_seed_type_fails_loudly(gpu):
+    d = M.workdir()
+    pre = os.path.join(d, "idx_alfalfa_amd_12")
+    if not os.path.exists(pre + ".aux"):
+        subprocess.run([M.GPU_EXE, "index", "-r", "reference.fasta", "-p", pre, "-s", "12"], cwd=d, check=True)
+    p = subprocess.run([M.GPU_EXE, "align", "-i", pre, "-0", "454reads.fq", "--seed", "MEM", "-o", os.path.join(d, "x.sam")], cwd=d,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"HIP kernel" in p.stderr
+
+
+def test_gpu_mapper_vs_oracle_mapper_synthetic(gpu):
+    """larger synthetic set (two contigs, short + long reads): product binary vs the oracle-backed host mapper"""
+    d = M.workdir()
+    rng = np.random.default_rng(11)
+    ref = seqgen.rand_ref(rng, 1500000)
+    ref2 = seqgen.rand_ref(rng, 200000)
+    with open(os.path.join(d, "syn.fa"), "w") as f:
+        for name, s in (("chr1", ref), ("chr2 comment", ref2)):
+            f.write(">%s\n" % name)
+            s = s.decode().upper()
+            for i in range(0, len(s), 60):
+                f.write(s[i:i + 60] + "\n")
+    cat = ref + b"a" * 50 + ref2
+
+    def fq(path, reads):
+        with open(os.path.join(d, path), "w") as f:
+            for i, r in enumerate(reads):
+                f.write("@r%d/1\n%s\n+\n%s\n" % (i, r.decode().upper(), "I" * len(r)))
+    fq("short.fq", seqgen.sim_reads(rng, cat, 20000, 250, 250, 0.02))
+    fq("long.fq", seqgen.sim_reads(rng, cat, 300, 2000, 8000, 0.10))
+    subprocess.run([M.GPU_EXE, "index", "-r", "syn.fa", "-p", "syn12", "-s", "12"], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+    for tag, args in (("short", ["-0", "short.fq"]), ("long", ["-0", "long.fq", "-e", "0.12"]), ("longdef", ["-0", "long.fq"])):
+        outs = []
+        for exe, thr in ((M.GPU_EXE, "4"), (M.CPU_EXE, "16")):
+            out = os.path.join(d, "syn_%s_%s.sam" % (tag, os.path.basename(exe)))
+            p = subprocess.run([exe, "align", "-i", "syn12", "-o", out, "-t", thr] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert p.returncode == 0, p.stderr.decode()[-2000:]
+            outs.append(M.sam_body(out))
+        assert outs[0] == outs[1], tag
+        assert outs[0].count(b"\n") > 100

@@ -1,0 +1,23 @@
+"""CPU test of the HOST LOGIC only: the mapper (regions, chaining, extension bookkeeping, CIGAR, MAPQ, SAM) linked
+against the oracle must reproduce the compiled reference's SAM byte for byte on every golden configuration.
+(The product binary links libalfa_hot instead; its parity is tests/test_gpu_mapper.py.)"""
+import os
+
+import pytest
+
+import mapper_util as M
+
+
+@pytest.mark.skipif(not os.path.exists(M.CPU_EXE), reason="tests/_cpu_mapper not built (run __graft_entry__.build())")
+@pytest.mark.parametrize("name", sorted(M.CONFIGS))
+def test_host_mapper_with_oracle_matches_reference_sam(name):
+    body = M.run_config(M.CPU_EXE, name, ["-t", "2", "--fibers", "64"])
+    assert M.md5(body) == M.golden_md5(name)
+    assert body == M.golden_body(name)
+
+
+@pytest.mark.skipif(not os.path.exists(M.CPU_EXE), reason="tests/_cpu_mapper not built")
+def test_output_independent_of_threads_and_fibers():
+    a = M.run_config(M.CPU_EXE, "pe_s12", ["-t", "1", "--fibers", "1"])
+    b = M.run_config(M.CPU_EXE, "pe_s12", ["-t", "5", "--fibers", "7"])
+    assert a == b == M.golden_body("pe_s12")
