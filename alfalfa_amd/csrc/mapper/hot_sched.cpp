@@ -13,7 +13,21 @@ namespace alfa {
 
 HotSched::HotSched(const HotOps& ops, const alfa_dp_params& prm, size_t stack_bytes) : ops_(ops), prm_(prm), stack_bytes_(stack_bytes) {}
 
+void HotSched::set_task_log(const std::string& prefix) {
+    log_hdr_ = fopen((prefix + ".hdr").c_str(), "wb");
+    log_seq_ = fopen((prefix + ".seq").c_str(), "wb");
+}
+
+void HotSched::log_task(int kind, const alfa_dp_task& t) {
+    int32_t h[5] = {kind, t.qlen, t.tlen, t.w, t.h0};
+    fwrite(h, 4, 5, log_hdr_);
+    fwrite(t.query, 1, (size_t)t.qlen, log_seq_);
+    fwrite(t.target, 1, (size_t)t.tlen, log_seq_);
+}
+
 HotSched::~HotSched() {
+    if (log_hdr_) fclose(log_hdr_);
+    if (log_seq_) fclose(log_seq_);
     for (auto& f : fibers_)
         if (f.stack) munmap(f.stack, stack_bytes_);
 }
@@ -68,7 +82,7 @@ void HotSched::flush() {
     if (!nw_.empty()) {
         std::vector<alfa_dp_task> t(nw_.size());
         std::vector<int32_t> s(nw_.size());
-        for (size_t i = 0; i < nw_.size(); ++i) t[i] = nw_[i].t;
+        for (size_t i = 0; i < nw_.size(); ++i) { t[i] = nw_[i].t; if (log_hdr_) log_task(0, t[i]); }
         int rc = ops_.ksw_nw_batch(&prm_, t.data(), (int)t.size(), s.data());
         if (rc) die(ops_, "alfa_ksw_nw_batch", rc);
         for (size_t i = 0; i < nw_.size(); ++i) *nw_[i].out = s[i];
@@ -78,7 +92,7 @@ void HotSched::flush() {
     if (!ext_.empty()) {
         std::vector<alfa_dp_task> t(ext_.size());
         std::vector<alfa_extend_result> r(ext_.size());
-        for (size_t i = 0; i < ext_.size(); ++i) t[i] = ext_[i].t;
+        for (size_t i = 0; i < ext_.size(); ++i) { t[i] = ext_[i].t; if (log_hdr_) log_task(2, t[i]); }
         int rc = ops_.ksw_extend_batch(&prm_, t.data(), (int)t.size(), r.data());
         if (rc) die(ops_, "alfa_ksw_extend_batch", rc);
         for (size_t i = 0; i < ext_.size(); ++i) *ext_[i].out = r[i];
@@ -89,7 +103,7 @@ void HotSched::flush() {
         std::vector<alfa_dp_task> t(glob_.size());
         std::vector<int32_t> s(glob_.size()), nc(glob_.size());
         std::vector<int64_t> off(glob_.size() + 1);
-        for (size_t i = 0; i < glob_.size(); ++i) t[i] = glob_[i].t;
+        for (size_t i = 0; i < glob_.size(); ++i) { t[i] = glob_[i].t; if (log_hdr_) log_task(1, t[i]); }
         uint32_t* cig = nullptr;
         int rc = ops_.ksw_global_batch(&prm_, t.data(), (int)t.size(), s.data(), &cig, nc.data(), off.data());
         if (rc) die(ops_, "alfa_ksw_global_batch", rc);

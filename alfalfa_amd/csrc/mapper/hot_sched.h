@@ -11,6 +11,7 @@
 #include <ucontext.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <functional>
 #include <string>
 #include <vector>
@@ -60,6 +61,9 @@ class HotSched {
     void submit_global(const GlobalReq& r) { glob_.push_back(r); }
     void wait();              // returns when every request submitted by this fiber has been answered
     const SchedStats& stats() const { return stats_; }
+    // when set, every DP task issued is appended to <prefix>.hdr (5 x int32: kind 0 nw|1 global|2 extend, qlen, tlen, w, h0)
+    // and <prefix>.seq (query bytes then target bytes); used by bench.py to replay the mapper's real task stream
+    void set_task_log(const std::string& prefix);
 
    private:
     struct Fiber { ucontext_t ctx; char* stack = nullptr; bool done = true; int job = -1; };
@@ -77,6 +81,9 @@ class HotSched {
     std::vector<NwReq> nw_;
     std::vector<GlobalReq> glob_;
     SchedStats stats_;
+    FILE* log_hdr_ = nullptr;
+    FILE* log_seq_ = nullptr;
+    void log_task(int kind, const alfa_dp_task& t);
 };
 
 }  // namespace alfa

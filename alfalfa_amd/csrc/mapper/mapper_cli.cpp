@@ -241,6 +241,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     Pool pool(T, [&](int t) {
         bind.bind_thread(o.device + t % G);
         scheds[t].reset(new HotSched(ops[t % G], prm));
+        if (const char* lp = getenv("ALFA_TASK_LOG")) scheds[t]->set_task_log(std::string(lp) + "." + std::to_string(t));
         mappers[t].reset(new Mapper(idx, o.aln, o.paired, *scheds[t]));
     });
     const int64_t bpCount = (int64_t)T * 10000000;   // BUFFER_SIZE src/main.cpp:54,116

@@ -308,6 +308,7 @@ DP_NW, DP_GLOBAL, DP_EXTEND = 0, 1, 2
 class DpBatch:
     def __init__(self, mode, params, tasks, device=0):
         self.mode, self.n = mode, len(tasks)
+        self._tasks = tasks
         h = C.c_void_p()
         check(lib().alfa_dp_batch_create(int(mode), C.byref(params), tasks, self.n, int(device), C.byref(h)))
         self._h = h

@@ -12,10 +12,9 @@ Workload = BASELINE.json configs[2] ("synthetic 5 Mbp random reference, 1M simul
 2% error, 1 GPU"): the configuration the metric is quoted on that fits one GPU.  configs[0]/[1] are the
 48 kbp lambda-phage walkthrough files (parity cases, not bench lines).
 
-DP task shapes: until the staged host mapper feeds its own task stream into the bench, the DP tasks of a
-read are drawn from its true alignment with the per-read call census of the reference measured in
-SURVEY.md 6 (0.8 ksw_nw, 0.86 ksw_extend, 1.7 ksw_global calls per 250 bp read, bands from the
-mapper's formulas); this is stated in the JSON line under config.dp_tasks.
+DP tasks are the real ones: before the timed region the product command line tool (alfalfa_amd align = staged host
+mapper + HIP hot path, byte-identical SAM to the reference) maps each step's reads once with ALFA_TASK_LOG set and
+every ksw_extend / ksw_nw / ksw_global task it issued is loaded, packed and made resident (mapper_dp_tasks()).
 """
 import argparse
 import json
@@ -76,39 +75,45 @@ def simulate_batch(rng, ref, n, rlen, err):
     return fw, rc, pos, strand
 
 
-def census_dp_tasks(rng, ref_nt4, fw, rc, pos, strand, edit_dist):
-    """DP tasks per read following the call census of SURVEY.md 6 (see module docstring)."""
+TASK_DTYPE = np.dtype([("query", "<u8"), ("target", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("h0", "<i4")])
+
+
+def mapper_dp_tasks(workdir, index_prefix, reads, threads=8):
+    """The DP task stream the staged host mapper really issues for `reads`: run the product command line tool
+    (alfalfa_amd align, HIP hot path) once with ALFA_TASK_LOG set and load every ksw_extend / ksw_nw / ksw_global
+    task it submitted.  Returns {kind: (ctypes DpTask array, keepalive)} for kind in extend/nw/global."""
+    import glob
+    import subprocess
     from alfalfa_amd import ffi
-    ext, nw, glob = [], [], []
-    ext_w, ext_h0, nw_w, glob_w = [], [], [], []
-    n = len(fw)
-    u = rng.random((n, 4))
-    lens = rng.integers(4, 60, (n, 4))
-    for i in range(n):
-        read = fw[i] if strand[i] else rc[i]          # the strand that matches the forward reference
-        rd = NT4[np.frombuffer(read, np.uint8)]
-        p = int(pos[i])
-        rl = len(rd)
-        if u[i, 0] < 0.86:   # one-sided extension: read overhang vs reference window of qlen+editDist
-            ql = int(lens[i, 0])
-            q = rd[rl - ql:]
-            t = ref_nt4[p + rl - ql - 2: p + rl + edit_dist]
-            ext.append((q, t)); ext_w.append(min(edit_dist, ql)); ext_h0.append(rl - ql)
-        if u[i, 1] < 0.8:    # inner chain gap
-            ql = int(lens[i, 1]); a = int(rng.integers(0, rl - ql))
-            q = rd[a:a + ql]
-            t = ref_nt4[p + a: p + a + ql + int(rng.integers(0, 3))]
-            nw.append((q, t)); nw_w.append(abs(len(q) - len(t)) + 3 + 3)
-        for k in (2, 3):     # CIGAR recovery gaps (1.7 per read)
-            if u[i, k] < 0.85:
-                ql = int(lens[i, k]); a = int(rng.integers(0, rl - ql))
-                q = rd[a:a + ql]
-                t = ref_nt4[p + a: p + a + ql + int(rng.integers(0, 3))]
-                glob.append((q, t)); glob_w.append(abs(len(q) - len(t)) + 3 + 4)
-    te, ke = ffi.make_dp_tasks(ext, ext_w, ext_h0)
-    tn, kn = ffi.make_dp_tasks(nw, nw_w, 0)
-    tg, kg = ffi.make_dp_tasks(glob, glob_w, 0)
-    return (te, ke), (tn, kn), (tg, kg)
+    fq = os.path.join(workdir, "step.fq")
+    with open(fq, "w") as f:
+        for i, r in enumerate(reads):
+            f.write("@r%d\n%s\n+\n%s\n" % (i, r.decode(), "I" * len(r)))
+    prefix = os.path.join(workdir, "tasks")
+    for old in glob.glob(prefix + ".*"):
+        os.remove(old)
+    exe = os.path.join(ROOT, "alfalfa_amd", "alfalfa_amd")
+    env = dict(os.environ, ALFA_TASK_LOG=prefix)
+    subprocess.run([exe, "align", "-i", index_prefix, "-0", fq, "-o", os.path.join(workdir, "step.sam"), "-t", str(threads)],
+                   check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    hdrs, seqs = [], []
+    for hf in sorted(glob.glob(prefix + ".*.hdr")):
+        hdrs.append(np.fromfile(hf, np.int32).reshape(-1, 5))
+        seqs.append(np.fromfile(hf[:-4] + ".seq", np.uint8))
+    hdr = np.concatenate(hdrs)
+    seq = np.concatenate(seqs)
+    off = np.concatenate([[0], np.cumsum(hdr[:, 1].astype(np.int64) + hdr[:, 2])[:-1]])
+    base = seq.ctypes.data
+    out = {}
+    for name, kind in (("nw", 0), ("global", 1), ("extend", 2)):
+        rows = np.nonzero(hdr[:, 0] == kind)[0]
+        arr = np.zeros(len(rows), dtype=TASK_DTYPE)
+        arr["query"] = base + off[rows]
+        arr["target"] = base + off[rows] + hdr[rows, 1]
+        arr["qlen"], arr["tlen"], arr["w"], arr["h0"] = hdr[rows, 1], hdr[rows, 2], hdr[rows, 3], hdr[rows, 4]
+        tasks = (ffi.DpTask * len(rows)).from_buffer(arr) if len(rows) else (ffi.DpTask * 0)()
+        out[name] = (tasks, (arr, seq))
+    return out
 
 
 def main():
@@ -123,6 +128,8 @@ def main():
     ap.add_argument("--sparseness", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20000)
+    ap.add_argument("--e2e-reads", type=int, default=300000, help="reads for the end-to-end command line comparison (0 = skip)")
+    ap.add_argument("--e2e-threads", type=int, default=16)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -149,6 +156,10 @@ def main():
     hidx = ffi.HostIndex.build_mem(["chr1"], [ref_bytes], K=K)
     didx = ffi.DeviceIndex(hidx, dev)
     t_index = time.time() - t0
+    import tempfile
+    workdir = tempfile.mkdtemp(prefix="alfa_bench_r%d_" % rank)
+    index_prefix = os.path.join(workdir, "idx")
+    hidx.save(index_prefix)
 
     err_percent = 0.08                           # reference default (src/options.cpp:52)
     min_len, sparse_q = seqgen.seed_params(K, args.read_len, err_percent)
@@ -162,7 +173,8 @@ def main():
         fw, rc, pos, strand = simulate_batch(rng, ref, args.batch, args.read_len, args.err)
         queries = ffi.make_seed_queries(fw + rc, min_len, 10000, sparse_q)
         plan = ffi.SeedPlan(didx, ffi.SEED_SMAM, queries)
-        (te, ke), (tn, kn), (tg, kg) = census_dp_tasks(rng, ref_nt4, fw, rc, pos, strand, edit_dist)
+        tk = mapper_dp_tasks(workdir, index_prefix, fw, threads=8)
+        (te, ke), (tn, kn), (tg, kg) = tk["extend"], tk["nw"], tk["global"]
         b_ext = ffi.DpBatch(ffi.DP_EXTEND, P, te, dev)
         b_nw = ffi.DpBatch(ffi.DP_NW, P, tn, dev)
         b_gl = ffi.DpBatch(ffi.DP_GLOBAL, P, tg, dev)
@@ -265,6 +277,32 @@ def main():
                "sample": "%d reads (both strands seeded + their DP tasks) of step 0, oracle/liboracle.so, 1 thread" % nsamp,
                "seed_reads_per_s": nsamp / tseed, "dp_gcups": cpu_cells / max(tcpu - tseed, 1e-9) / 1e9}
 
+    # ---- end-to-end wall clock of the command line tools (FASTQ in -> SAM out, index load included): informative only,
+    # never `value`.  The reference executable compiled from /root/reference (oracle/_ref/alfalfa) travels with the tree.
+    e2e = None
+    if args.e2e_reads > 0:
+        import hashlib
+        import subprocess
+        er, _, _, _ = simulate_batch(np.random.default_rng(77), ref, args.e2e_reads, args.read_len, args.err)
+        fq = os.path.join(workdir, "e2e.fq")
+        with open(fq, "w") as f:
+            for i, r in enumerate(er):
+                f.write("@r%d\n%s\n+\n%s\n" % (i, r.decode(), "I" * len(r)))
+        e2e = {"reads": args.e2e_reads, "threads": args.e2e_threads}
+        for name, exe in (("alfalfa_amd_gpu", os.path.join(ROOT, "alfalfa_amd", "alfalfa_amd")),
+                          ("reference_cpu", os.path.join(ROOT, "oracle", "_ref", "alfalfa"))):
+            if not os.path.exists(exe):
+                continue
+            outp = os.path.join(workdir, name + ".sam")
+            tt = time.perf_counter()
+            pr = subprocess.run([exe, "align", "-i", index_prefix, "-0", fq, "-o", outp, "-t", str(args.e2e_threads)],
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dt = time.perf_counter() - tt
+            body = b"\n".join(l for l in open(outp, "rb").read().split(b"\n") if not l.startswith(b"@PG"))
+            e2e[name] = {"seconds": dt, "reads_per_s": args.e2e_reads / dt, "rc": pr.returncode, "sam_md5": hashlib.md5(body).hexdigest()}
+        if "reference_cpu" in e2e and "alfalfa_amd_gpu" in e2e:
+            e2e["sam_identical"] = e2e["reference_cpu"]["sam_md5"] == e2e["alfalfa_amd_gpu"]["sam_md5"]
+
     total_reads = args.batch * args.steps * world
     dp_ms = sum(ext_ms) + sum(nw_ms) + sum(gl_ms)
     out = {
@@ -285,8 +323,9 @@ def main():
                         "index sparseness K=%d, %d reads per step per GPU, %d timed steps" %
                         (args.ref_len, args.read_len, args.err * 100, K, args.batch, args.steps),
             "seed_type": "SMAM (CLI --seed SMEM default), min_len=%d sparseQ=%d maxCount=10000, fw+rc" % (min_len, sparse_q),
-            "dp_tasks": "per-read call census of SURVEY.md 6 drawn from the true alignment (0.86 ksw_extend, 0.8 ksw_nw, "
-                        "1.7 ksw_global per read); host mapper not in the timed region",
+            "dp_tasks": "every ksw_extend/ksw_nw/ksw_global task the staged host mapper (alfalfa_amd align) issues for the step's "
+                        "reads, captured before the timed region and replayed resident; %.2f/%.2f/%.2f tasks per read" %
+                        (len(timed[0][1]._tasks) / args.batch, len(timed[0][2]._tasks) / args.batch, len(timed[0][3]._tasks) / args.batch),
             "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world,
         },
         "device_ms_total": dev_ms,
@@ -313,6 +352,7 @@ def main():
             "avg_launch_ms": seed_avg_ms,
         },
         "cpu_baseline": cpu,
+        "end_to_end_cli": e2e,
     }
     print(json.dumps(out))
     if world > 1:

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""End-to-end wall-clock of the command line tools on a synthetic workload (FASTQ in -> SAM out, index load included).
+usage: e2e_bench.py [--reads N] [--threads T] [--ref-len L] [--read-len R | --long] [--err E] [--exe gpu|cpu|ref] ..."""
+import argparse
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench  # noqa: E402
+import seqgen  # noqa: E402
+
+EXES = {"gpu": os.path.join(ROOT, "alfalfa_amd", "alfalfa_amd"), "cpu": os.path.join(ROOT, "tests", "_cpu_mapper"),
+        "ref": os.path.join(ROOT, "oracle", "_ref", "alfalfa")}
+
+
+def write_workload(d, ref_len, n, read_len, err, long_reads, seed=1):
+    ref = bench.make_reference(ref_len, seed)
+    fa = os.path.join(d, "ref.fa")
+    with open(fa, "w") as f:
+        f.write(">chr1\n")
+        s = ref.tobytes().decode().upper()
+        f.write("\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + "\n")
+    rng = np.random.default_rng(seed + 100)
+    fq = os.path.join(d, "reads.fq")
+    with open(fq, "w") as f:
+        if long_reads:
+            reads = seqgen.sim_reads(rng, ref.tobytes(), n, 2000, 10000, err)
+        else:
+            reads, _, _, _ = bench.simulate_batch(rng, ref, n, read_len, err)
+        for i, r in enumerate(reads):
+            f.write("@r%d\n%s\n+\n%s\n" % (i, r.decode().upper(), "I" * len(r)))
+    return fa, fq
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=200000)
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--ref-len", type=int, default=5000000)
+    ap.add_argument("--read-len", type=int, default=250)
+    ap.add_argument("--err", type=float, default=0.02)
+    ap.add_argument("--long", action="store_true")
+    ap.add_argument("--exe", default="gpu,cpu")
+    ap.add_argument("--extra", default="")
+    ap.add_argument("--dir", default="/tmp/alfa_e2e")
+    args = ap.parse_args()
+    os.makedirs(args.dir, exist_ok=True)
+    fa, fq = write_workload(args.dir, args.ref_len, args.reads, args.read_len, args.err, args.long)
+    idx = os.path.join(args.dir, "idx12")
+    subprocess.run([EXES["cpu"] if os.path.exists(EXES["cpu"]) else EXES["gpu"], "index", "-r", fa, "-p", idx, "-s", "12"], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    md5s = {}
+    for name in args.exe.split(","):
+        exe = EXES[name]
+        if not os.path.exists(exe):
+            print(name, "missing")
+            continue
+        out = os.path.join(args.dir, "out_%s.sam" % name)
+        cmd = [exe, "align", "-i", idx, "-0", fq, "-o", out, "-t", str(args.threads)] + args.extra.split()
+        if name != "ref":
+            cmd.append("--stats")
+        t0 = time.time()
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        dt = time.time() - t0
+        stats = [l for l in p.stderr.decode().split("\n") if l.startswith("#STATS")]
+        import hashlib
+        body = b"\n".join(l for l in open(out, "rb").read().split(b"\n") if not l.startswith(b"@PG"))
+        md5s[name] = hashlib.md5(body).hexdigest()
+        print("%s rc=%d %.2fs %.0f reads/s md5=%s %s" % (name, p.returncode, dt, args.reads / dt, md5s[name], " ".join(stats)), flush=True)
+    print("identical:", len(set(md5s.values())) == 1)
+
+
+if __name__ == "__main__":
+    main()
