@@ -6,11 +6,28 @@
 #include <cstring>
 #include <list>
 #include <map>
-#include <sstream>
+#include <charconv>
+#include <type_traits>
 
 namespace alfa {
 
 namespace {
+
+// append-only text builder with the stream syntax the SAM/CIGAR code uses (decimal integers, chars, strings)
+struct Txt {
+    std::string s;
+    Txt& operator<<(const std::string& v) { s += v; return *this; }
+    Txt& operator<<(const char* v) { s += v; return *this; }
+    Txt& operator<<(char v) { s += v; return *this; }
+    template <class I, class = typename std::enable_if<std::is_integral<I>::value>::type>
+    Txt& operator<<(I v) {
+        char b[24];
+        auto r = std::to_chars(b, b + sizeof(b), v);
+        s.append(b, (size_t)(r.ptr - b));
+        return *this;
+    }
+    std::string& str() { return s; }
+};
 
 const int MIN_SEED_LENGTH = 20;   // src/mapper.cpp:36
 const int MAX_MAPQ = 60;          // :37
@@ -52,7 +69,7 @@ int band_estimate(int fixedBand, int qLen, int refLen, int matchScore, int gapOp
 }
 
 // recoverCIGAR4 src/mapper.cpp:80-117 (also the body of setFieldsKsw :128-162)
-int cigar4(const std::vector<uint32_t>& bam, const uint8_t* query, const uint8_t* rseq, std::ostringstream& sNM, std::ostringstream* sCig) {
+int cigar4(const std::vector<uint32_t>& bam, const uint8_t* query, const uint8_t* rseq, Txt& sNM, Txt* sCig) {
     int x = 0, y = 0, n_mm = 0, n_gap = 0;
     for (size_t k = 0; k < bam.size(); ++k) {
         int op = bam[k] & 0xf;
@@ -83,7 +100,7 @@ int cigar4(const std::vector<uint32_t>& bam, const uint8_t* query, const uint8_t
 
 // recoverCIGAR3from4 src/mapper.cpp:54-77
 std::string cigar3_from4(const std::string& c4) {
-    std::ostringstream out;
+    Txt out;
     size_t p = 0;
     long matchLength = 0;
     while (p < c4.size()) {
@@ -100,7 +117,7 @@ std::string cigar3_from4(const std::string& c4) {
         p = q + 1;
     }
     if (matchLength > 0) out << matchLength << 'M';
-    return out.str();
+    return std::move(out.s);
 }
 
 bool cmp_matches(const Match& i, const Match& j) { return i.ref < j.ref || (i.ref == j.ref && i.query < j.query); }            // compMatches :570
@@ -150,36 +167,36 @@ void Read::init() {
 
 // read_t::emptyAlingment src/mapper.h:170-179
 std::string Read::emptyAlignment(bool paired, bool mateFailed, bool upstream) const {
-    std::ostringstream ss;
+    Txt ss;
     int flag = 4;
     if (paired) flag += 1;
     if (mateFailed) flag += 8;
     if (paired && upstream) flag += 64;
     if (paired && !upstream) flag += 128;
     ss << qname << "\t" << flag << "\t*\t0\t0\t*\t*\t0\t0\t" << sequence << "\t" << qual << "\n";
-    return ss.str();
+    return std::move(ss.s);
 }
 
 // read_t::printUnpairedAlignment src/mapper.h:181-193
 std::string Read::printUnpaired(int i) const {
-    std::ostringstream ss;
+    Txt ss;
     const Alignment* a = alignments[i];
     ss << qname << "\t" << (unsigned long)a->flag << "\t" << a->rname << "\t" << a->pos << "\t" << a->mapq << "\t" << a->cigar << "\t"
        << "*" << "\t" << 0 << "\t" << 0 << "\t" << (a->rc() ? rcSequence : sequence) << "\t" << (a->rc() ? rQual : qual) << "\tAS:i:"
        << a->alignmentScore << "\tNM:i:" << a->editDist << "\tX0:Z:" << a->NMtag << "\n";
-    return ss.str();
+    return std::move(ss.s);
 }
 
 // read_t::printPairedAlignments src/mapper.h:196-215
 std::string Read::printPaired(int i, bool firstMate) {
     Alignment* a = alignments[i];
     if (a->paired()) {
-        std::ostringstream ss;
+        Txt ss;
         ss << qname << "\t" << (unsigned long)(a->flag | a->mate.flag) << "\t" << a->rname << "\t" << a->pos << "\t" << a->mapq << "\t"
            << a->cigar << "\t" << (a->rname == a->mate.rnext ? "=" : a->mate.rnext) << "\t" << a->mate.pnext << "\t" << a->mate.tLength
            << "\t" << (a->rc() ? rcSequence : sequence) << "\t" << (a->rc() ? rQual : qual) << "\tAS:i:"
            << a->alignmentScore + a->mate.alignmentScore << "\tNM:i:" << a->editDist << "\tX0:Z:" << a->NMtag << "\n";
-        return ss.str();
+        return std::move(ss.s);
     }
     // alignment_t::setUnPaired src/mapper.h:114-119
     a->flag |= 1u;
@@ -191,7 +208,7 @@ std::string Read::printPaired(int i, bool firstMate) {
 
 // createHeader src/main.cpp:266-283
 std::string sam_header(const RefIndex& idx, int argc, char** argv) {
-    std::ostringstream ss;
+    Txt ss;
     ss << "@HD\tVN:1.3\n";
     const int n = idx.v->n_seq;
     for (int i = 0; i + 1 < n; i++) ss << "@SQ\tSN:" << idx.descr(i) << "\tLN:" << (idx.v->startpos[i + 1] - idx.v->startpos[i] - 1) << "\n";
@@ -199,7 +216,7 @@ std::string sam_header(const RefIndex& idx, int argc, char** argv) {
     ss << "@PG\tID:alfalfa\tCL:";
     for (int i = 0; i < argc; i++) { if (i > 0) ss << " "; ss << argv[i]; }
     ss << "\tVN:0.8.1-mi355x\n";
-    return ss.str();
+    return std::move(ss.s);
 }
 
 // ------------------------------------------------------------------------------------------ seeds
@@ -689,7 +706,7 @@ void Mapper::postprocess(Read& read, bool paired) {
         const uint8_t* target = pl.target.data();
         if (!a.chain.empty() && !opt_.fullDP) {
             auto lit = [&](const std::string& s, int e) { pl.pieces.push_back(Piece{0, s, -1, e}); };
-            auto num = [](long v, char c) { std::ostringstream o; o << v << c; return o.str(); };
+            auto num = [](long v, char c) { Txt o; o << v << c; return std::move(o.s); };
             if (a.qB) lit(num(a.qB, 'S'), 0);
             const std::vector<Match>& ch = a.chain;
             if (ch[0].query > a.qB) {
@@ -740,7 +757,7 @@ void Mapper::postprocess(Read& read, bool paired) {
         Alignment& a = *al[j];
         Plan& pl = plans[j];
         if (!pl.full) {
-            std::ostringstream sNM;
+            Txt sNM;
             a.editDist = 0;
             for (const Piece& p : pl.pieces) {
                 if (p.kind == 0) { sNM << p.lit; a.editDist += p.editAdd; }
@@ -752,7 +769,7 @@ void Mapper::postprocess(Read& read, bool paired) {
             // fullDP + setFieldsKsw src/mapper.cpp:120-170,303-320
             DpJob& d = *jobv[pl.fullJob];
             a.alignmentScore = d.score;
-            std::ostringstream sNM, sCig;
+            Txt sNM, sCig;
             int beginGap = a.qB, endGap = Plen - 1 - a.qE;
             if (beginGap) { sCig << beginGap << "S"; sNM << beginGap << "S"; }
             a.editDist = cigar4(d.cigar, d.q, d.t, sNM, &sCig);

@@ -8,8 +8,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
+#include <chrono>
 
 #include "../seqio.h"
 
@@ -186,6 +189,39 @@ class Pool {
     bool stop_ = false;
 };
 
+// bounded hand-off queue between the pipeline stages
+template <class T>
+class Chan {
+   public:
+    explicit Chan(size_t cap) : cap_(cap) {}
+    void push(T v) {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return q_.size() < cap_; });
+        q_.push_back(std::move(v));
+        cv_.notify_all();
+    }
+    bool pop(T& v) {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        v = std::move(q_.front());
+        q_.pop_front();
+        cv_.notify_all();
+        return true;
+    }
+    void close() {
+        std::lock_guard<std::mutex> g(mu_);
+        closed_ = true;
+        cv_.notify_all();
+    }
+   private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+    size_t cap_;
+    bool closed_ = false;
+};
+
 }  // namespace
 
 int mapper_main(int argc, char** argv, const HotBinding& bind) {
@@ -244,85 +280,142 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         if (const char* lp = getenv("ALFA_TASK_LOG")) scheds[t]->set_task_log(std::string(lp) + "." + std::to_string(t));
         mappers[t].reset(new Mapper(idx, o.aln, o.paired, *scheds[t]));
     });
-    const int64_t bpCount = (int64_t)T * 10000000;   // BUFFER_SIZE src/main.cpp:54,116
+    // Batches follow the reference's driver (BUFFER_SIZE bases per thread, src/main.cpp:54,116) but are also capped at one
+    // wave of fibers per worker so that parsing (reader thread), mapping + SAM rendering (worker pool) and writing
+    // (writer thread) of successive batches overlap.  Batch boundaries do not influence the output.
+    const int64_t bpCount = (int64_t)T * 10000000;
+    const size_t readCap = (size_t)T * (size_t)std::max(256, o.fibers);
 
+    struct Batch {
+        std::vector<Read> a, b;               // b stays empty for single-end input
+        std::vector<std::string> text;        // rendered SAM, one chunk per worker slice, in input order
+        std::vector<long> cnt;                // per slice: mapped1, printed1, mapped2, printed2
+    };
+    typedef std::unique_ptr<Batch> BatchP;
     long total = 0, mapped1 = 0, mapped2 = 0, printed1 = 0, printed2 = 0;
+    double t_parse = 0, t_map = 0, t_print = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+
+    // fill(batch) -> false at end of input; work(batch, t, lo, hi) maps and renders reads [lo,hi) on worker t
+    auto stream = [&](const std::function<bool(Batch&)>& fill, const std::function<void(Batch&, int, int, int)>& work) {
+        Chan<BatchP> parsed(2), mapped(2);
+        std::thread reader([&] {
+            for (;;) {
+                double t0 = now();
+                BatchP bp(new Batch);
+                bool ok = fill(*bp);
+                t_parse += now() - t0;
+                if (!ok) break;
+                parsed.push(std::move(bp));
+            }
+            parsed.close();
+        });
+        std::thread writer([&] {
+            BatchP bp;
+            while (mapped.pop(bp)) {
+                double t0 = now();
+                for (const std::string& s : bp->text) fwrite(s.data(), 1, s.size(), out);
+                bp.reset();                    // frees the reads and their alignments off the mapping threads
+                t_print += now() - t0;
+            }
+        });
+        BatchP bp;
+        while (parsed.pop(bp)) {
+            double t0 = now();
+            Batch& B = *bp;
+            const int n = (int)B.a.size();
+            total += n;
+            B.text.assign((size_t)T, std::string());
+            B.cnt.assign((size_t)T * 4, 0);
+            pool.run([&](int t) { work(B, t, (int)((int64_t)n * t / T), (int)((int64_t)n * (t + 1) / T)); });
+            for (int t = 0; t < T; ++t) {
+                mapped1 += B.cnt[t * 4]; printed1 += B.cnt[t * 4 + 1]; mapped2 += B.cnt[t * 4 + 2]; printed2 += B.cnt[t * 4 + 3];
+            }
+            t_map += now() - t0;
+            mapped.push(std::move(bp));
+        }
+        mapped.close();
+        reader.join();
+        writer.join();
+    };
+
     if (!o.unpairedQ.empty()) {
         SeqReader rd;
         if (!rd.open(o.unpairedQ.c_str())) { fprintf(stderr, "ERROR: file %s could not be read.", o.unpairedQ.c_str()); return 1; }
-        for (;;) {
-            std::vector<Read> reads;
-            int64_t cur = 0;
-            while (cur < bpCount) {
-                Read r;
-                if (!next_read(rd, r)) break;
-                cur += (int64_t)r.sequence.length();
-                reads.push_back(std::move(r));
-            }
-            if (reads.empty()) break;
-            const int n = (int)reads.size();
-            total += n;
-            pool.run([&](int t) {
-                const int lo = (int)((int64_t)n * t / T), hi = (int)((int64_t)n * (t + 1) / T);
-                Mapper& mp = *mappers[t];
-                scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.map_unpaired(reads[lo + i]); });
-            });
-            for (int i = 0; i < n; i++) {
-                if (reads[i].alignments.empty()) fputs(reads[i].emptyAlignment(false, false, true).c_str(), out);
-                else {
-                    mapped1++;
-                    int k = std::min((int)reads[i].alignments.size(), o.aln.alignmentCount);
-                    printed1 += k;
-                    for (int j = 0; j < k; j++) fputs(reads[i].printUnpaired(j).c_str(), out);
+        stream(
+            [&](Batch& B) {
+                int64_t cur = 0;
+                while (cur < bpCount && B.a.size() < readCap) {
+                    Read r;
+                    if (!next_read(rd, r)) break;
+                    cur += (int64_t)r.sequence.length();
+                    B.a.push_back(std::move(r));
                 }
-            }
-        }
+                return !B.a.empty();
+            },
+            [&](Batch& B, int t, int lo, int hi) {
+                Mapper& mp = *mappers[t];
+                std::string& txt = B.text[t];
+                long* c = &B.cnt[(size_t)t * 4];
+                scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.map_unpaired(B.a[lo + i]); });
+                for (int i = lo; i < hi; i++) {
+                    Read& r = B.a[i];
+                    if (r.alignments.empty()) txt += r.emptyAlignment(false, false, true);
+                    else {
+                        c[0]++;
+                        int k = std::min((int)r.alignments.size(), o.aln.alignmentCount);
+                        c[1] += k;
+                        for (int j = 0; j < k; j++) txt += r.printUnpaired(j);
+                    }
+                }
+            });
         printf("sequences read: %ld\nsequences mapped: %ld\nalignments printed: %ld\n", total, mapped1, printed1);
     }
     if (!o.pair1.empty() && !o.pair2.empty()) {
         SeqReader r1, r2;
         if (!r1.open(o.pair1.c_str()) || !r2.open(o.pair2.c_str())) { fprintf(stderr, "ERROR: mate files could not be read."); return 1; }
-        total = mapped1 = printed1 = 0;
-        for (;;) {
-            std::vector<Read> m1, m2;
-            int64_t cur = 0;
-            while (cur < bpCount) {
-                Read a, b;
-                bool ok1 = next_read(r1, a);
-                bool ok2 = next_read(r2, b);     // the reference keeps only the second status (src/main.cpp:157-158)
-                (void)ok1;
-                if (!ok2) break;
-                cur += (int64_t)a.sequence.length();
-                m1.push_back(std::move(a));
-                m2.push_back(std::move(b));
-            }
-            if (m1.empty()) break;
-            const int n = (int)m1.size();
-            total += n;
-            pool.run([&](int t) {
-                const int lo = (int)((int64_t)n * t / T), hi = (int)((int64_t)n * (t + 1) / T);
+        total = mapped1 = printed1 = mapped2 = printed2 = 0;
+        stream(
+            [&](Batch& B) {
+                int64_t cur = 0;
+                while (cur < bpCount && B.a.size() < readCap) {
+                    Read a, b;
+                    bool ok1 = next_read(r1, a);
+                    bool ok2 = next_read(r2, b);     // the reference keeps only the second status (src/main.cpp:157-158)
+                    (void)ok1;
+                    if (!ok2) break;
+                    cur += (int64_t)a.sequence.length();
+                    B.a.push_back(std::move(a));
+                    B.b.push_back(std::move(b));
+                }
+                return !B.a.empty();
+            },
+            [&](Batch& B, int t, int lo, int hi) {
                 Mapper& mp = *mappers[t];
-                scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.map_paired(m1[lo + i], m2[lo + i]); });
+                std::string& txt = B.text[t];
+                long* c = &B.cnt[(size_t)t * 4];
+                scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.map_paired(B.a[lo + i], B.b[lo + i]); });
+                for (int i = lo; i < hi; i++) {
+                    Read& m1 = B.a[i];
+                    Read& m2 = B.b[i];
+                    if (m1.alignments.empty()) txt += m1.emptyAlignment(true, m2.alignments.empty(), true);
+                    else {
+                        c[0]++;
+                        int k = o.paired.mixed ? std::min((int)m1.alignments.size(), o.aln.alignmentCount)
+                                               : std::min(m1.pairedAlignmentCount, o.aln.alignmentCount);
+                        c[1] += k;
+                        for (int j = 0; j < k; j++) txt += m1.printPaired(j, true);
+                    }
+                    if (m2.alignments.empty()) txt += m2.emptyAlignment(true, m1.alignments.empty(), false);
+                    else {
+                        c[2]++;
+                        int k = o.paired.mixed ? std::min((int)m2.alignments.size(), o.aln.alignmentCount)
+                                               : std::min(m2.pairedAlignmentCount, o.aln.alignmentCount);
+                        c[3] += k;
+                        for (int j = 0; j < k; j++) txt += m2.printPaired(j, false);
+                    }
+                }
             });
-            for (int i = 0; i < n; i++) {
-                if (m1[i].alignments.empty()) fputs(m1[i].emptyAlignment(true, m2[i].alignments.empty(), true).c_str(), out);
-                else {
-                    mapped1++;
-                    int k = o.paired.mixed ? std::min((int)m1[i].alignments.size(), o.aln.alignmentCount)
-                                           : std::min(m1[i].pairedAlignmentCount, o.aln.alignmentCount);
-                    printed1 += k;
-                    for (int j = 0; j < k; j++) fputs(m1[i].printPaired(j, true).c_str(), out);
-                }
-                if (m2[i].alignments.empty()) fputs(m2[i].emptyAlignment(true, m1[i].alignments.empty(), false).c_str(), out);
-                else {
-                    mapped2++;
-                    int k = o.paired.mixed ? std::min((int)m2[i].alignments.size(), o.aln.alignmentCount)
-                                           : std::min(m2[i].pairedAlignmentCount, o.aln.alignmentCount);
-                    printed2 += k;
-                    for (int j = 0; j < k; j++) fputs(m2[i].printPaired(j, false).c_str(), out);
-                }
-            }
-        }
         printf("sequences read: %ld\nsequences mapped (mate1): %ld\nsequences mapped (mate2): %ld\n"
                "alignments printed (mate1): %ld\nalignments printed (mate2): %ld\n", total, mapped1, mapped2, printed1, printed2);
     }
@@ -335,6 +428,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
             s.ext_tasks += x.ext_tasks; s.nw_calls += x.nw_calls; s.nw_tasks += x.nw_tasks; s.glob_calls += x.glob_calls;
             s.glob_tasks += x.glob_tasks; s.hot_seconds += x.hot_seconds;
         }
+        fprintf(stderr, "#PHASES parse %.3f map %.3f print %.3f\n", t_parse, t_map, t_print);
         fprintf(stderr, "#STATS rounds %ld seed_calls %ld seed_queries %ld extend %ld/%ld nw %ld/%ld global %ld/%ld hot_seconds %.3f\n",
                 (long)s.rounds, (long)s.seed_calls, (long)s.seed_queries, (long)s.ext_calls, (long)s.ext_tasks, (long)s.nw_calls,
                 (long)s.nw_tasks, (long)s.glob_calls, (long)s.glob_tasks, s.hot_seconds);

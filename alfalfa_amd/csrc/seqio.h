@@ -10,6 +10,7 @@
 #include <zlib.h>
 
 #include <cctype>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -21,22 +22,28 @@ struct SeqRecord {
 
 class SeqReader {
    public:
+    ~SeqReader() { close(); }
     bool open(const char* path) {
-        gzFile f = gzopen(path, "r");
-        if (!f) return false;
-        buf_.clear();
-        std::vector<char> chunk(1 << 20);
-        int got;
-        while ((got = gzread(f, chunk.data(), (unsigned)chunk.size())) > 0) buf_.insert(buf_.end(), chunk.data(), chunk.data() + got);
-        gzclose(f);
-        pos_ = 0;
+        close();
+        f_ = gzopen(path, "r");
+        if (!f_) return false;
+        gzbuffer(f_, 1 << 20);
+        buf_.resize(1 << 22);
+        beg_ = end_ = 0;
+        eof_ = false;
         last_char_ = 0;
         return true;
     }
     void open_mem(const char* data, size_t n) {
+        close();
         buf_.assign(data, data + n);
-        pos_ = 0;
+        beg_ = 0; end_ = n;
+        eof_ = true;
         last_char_ = 0;
+    }
+    void close() {
+        if (f_) gzclose(f_);
+        f_ = nullptr;
     }
     // returns sequence length, -1 at EOF, -2 on truncated quality
     long next(SeqRecord& r) {
@@ -66,31 +73,52 @@ class SeqReader {
     }
 
    private:
-    int getc_() { return pos_ < buf_.size() ? (unsigned char)buf_[pos_++] : -1; }
+    bool fill() {   // true when at least one unread byte is available
+        if (beg_ < end_) return true;
+        if (eof_) return false;
+        int got = gzread(f_, buf_.data(), (unsigned)buf_.size());
+        beg_ = 0;
+        end_ = got > 0 ? (size_t)got : 0;
+        if (end_ < buf_.size()) eof_ = true;
+        return end_ > 0;
+    }
+    int getc_() { return fill() ? (unsigned char)buf_[beg_++] : -1; }
     // ks_getuntil(ks, KS_SEP_SPACE): false only when already at EOF
     bool until_space(std::string& s, int& delim) {
         s.clear();
         delim = 0;
-        if (pos_ >= buf_.size()) return false;
-        size_t i = pos_;
-        while (i < buf_.size() && !isspace((unsigned char)buf_[i])) i++;
-        s.assign(buf_.data() + pos_, i - pos_);
-        if (i < buf_.size()) delim = (unsigned char)buf_[i];
-        pos_ = i + 1;
-        return true;
+        if (!fill()) return false;
+        for (;;) {
+            size_t i = beg_;
+            while (i < end_ && !isspace((unsigned char)buf_[i])) i++;
+            s.append(buf_.data() + beg_, i - beg_);
+            if (i < end_) { delim = (unsigned char)buf_[i]; beg_ = i + 1; return true; }
+            beg_ = end_;
+            if (!fill()) return true;
+        }
     }
     // ks_getuntil2(ks, KS_SEP_LINE, str, 0, append=1): false at EOF with nothing left
     bool until_line(std::string& s) {
-        if (pos_ >= buf_.size()) return false;
-        size_t i = pos_;
-        while (i < buf_.size() && buf_[i] != '\n') i++;
-        s.append(buf_.data() + pos_, i - pos_);
-        pos_ = i + 1;
+        if (!fill()) return false;
+        for (;;) {
+            const char* p = buf_.data() + beg_;
+            const char* nl = (const char*)memchr(p, '\n', end_ - beg_);
+            if (nl) {
+                s.append(p, (size_t)(nl - p));
+                beg_ = (size_t)(nl - buf_.data()) + 1;
+                break;
+            }
+            s.append(p, end_ - beg_);
+            beg_ = end_;
+            if (!fill()) break;
+        }
         if (s.size() > 1 && s.back() == '\r') s.pop_back();
         return true;
     }
+    gzFile f_ = nullptr;
     std::vector<char> buf_;
-    size_t pos_ = 0;
+    size_t beg_ = 0, end_ = 0;
+    bool eof_ = true;
     int last_char_ = 0;
 };
 
