@@ -16,6 +16,14 @@
 //   scan      exclusive sum of the per-read totals
 //   kernel B  one lane per work-list record re-enumerates its SA interval, left-extends
 //             (find_LmaximalStrict) and writes match_t records at base[read] + offset
+//
+// The other seed types use the same count / scan / emit structure:
+//   MEM   (sparseSA::MEM  :1116-1119 -> findMEM :993-1060 -> collectAllMEMs :873-899), CLI "--seed MEM"
+//   SMEM  (sparseSA::SMEM :1127-1208 -> collectXmiAndMli :910-966), CLI "--seed PSMEM": the per-read second phase
+//         (tuples ordered by end position, beginLong/smemCount tables, the curMinPos sweep) runs on one lane of the
+//         read's workgroup between the parallel traversal and the parallel counting stages.
+// Indexes without a child table (--no-child) take the binary-search descent (traverse :701-728, top_down_faster :614-666)
+// for SMAM and MEM.  Suffix-link indexes and SMEMP (unreachable from the reference's command line) have no kernel.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -46,15 +54,25 @@ struct DIdx {
     const int32_t* __restrict__ CHILD;
     const uint2* __restrict__ KMR;
     int64_t N;
-    int32_t n, nM, K, has_kmer;
+    int32_t n, nM, K, has_kmer, has_child;
 };
 
 struct SeedQ {          // one sparseSA::SMAM(P, ...) call
     int64_t poff;       // offset of P in the packed read buffer
     int32_t plen, min_len, max_count, sparse_q;
     int32_t npref;      // number of prefix queries of this call
-    int32_t pad;
+    int32_t max_smem;   // max_smem_cont (SMEM only)
+    int64_t soff;       // SMEM: offset (in ints) of this read's tables in the global scratch, when they do not fit in LDS
 };
+
+struct WorkRec2 {       // MEM / SMEM: one emitting prefix query with both of its intervals
+    int32_t read, woff, prefix;
+    int32_t ms, me, md;        // mli
+    int32_t xs, xe, xd;        // xmi
+    int32_t calc, nes, nesp;   // SMEM: calcMli, nextEndStop, nextEndStopPrefix
+};
+
+struct IvalD { int start, end, depth; };
 
 struct WorkRec {        // one emitting prefix query
     int32_t read, woff, start, end, depth, prefix;
@@ -169,6 +187,146 @@ __device__ __forceinline__ bool lmax_strict(const DIdx& X, const PAT& P, int pre
     return false;
 }
 
+// top_down_faster  sparseSA.cpp:614-666 (binary search on the i-th character, no child table)
+__device__ bool td_binary(const DIdx& X, uint32_t c, int i, int& start, int& end) {
+    int l, r, m, r2 = end, l2 = start;
+    bool found = false;
+    const int cmp_first = (int)c - (int)d_s(X, (int64_t)X.SA[start] + i);
+    const int cmp_last = (int)c - (int)d_s(X, (int64_t)X.SA[end] + i);
+    if (cmp_first < 0) { l = start + 1; l2 = start; }
+    else if (cmp_last > 0) { l = end + 1; l2 = end; }
+    else {
+        l = start; r = end;
+        if (cmp_first == 0) { found = true; r2 = r; }
+        else {
+            while (r - l > 1) {
+                m = (l + r) / 2;
+                const int vgl = (int)c - (int)d_s(X, (int64_t)X.SA[m] + i);
+                if (vgl <= 0) {
+                    if (!found && vgl == 0) { found = true; l2 = m; r2 = r; }
+                    r = m;
+                } else l = m;
+            }
+            l = r;
+        }
+        if (!found) l2 = l - 1;
+        if (cmp_last == 0) l2 = end;
+        else {
+            while (r2 - l2 > 1) {
+                m = (l2 + r2) / 2;
+                const int vgl = (int)c - (int)d_s(X, (int64_t)X.SA[m] + i);
+                if (vgl < 0) r2 = m; else l2 = m;
+            }
+        }
+    }
+    start = l; end = l2;
+    return l <= l2;
+}
+
+// traverse  sparseSA.cpp:701-728 with maxBranching = -1
+__device__ void traverse_plain(const DIdx& X, const PatD& P, int prefix, int& start, int& end, int& depth, int min_len) {
+    if (X.has_kmer && depth == 0 && min_len >= KMER) {
+        uint32_t index = 0;
+#pragma unroll
+        for (int i = 0; i < KMER; ++i) index = (index << 2) | bitadd(P.at(prefix + i));
+        if (index >= TABLE) return;
+        const uint2 lr = X.KMR[index];
+        if (lr.y == 0) return;
+        depth = KMER; start = (int)lr.x; end = (int)lr.y;
+    }
+    if (depth >= min_len) return;
+    while (prefix + depth < P.len) {
+        int s2 = start, e2 = end;
+        if (!td_binary(X, P.at(prefix + depth), depth, s2, e2)) return;
+        ++depth; start = s2; end = e2;
+        if (depth == min_len) return;
+    }
+}
+
+__device__ __forceinline__ void traverse_any(const DIdx& X, const PatD& P, int prefix, IvalD& v, int min_len) {
+    if (X.has_child) traverse_child(X, P, prefix, v.start, v.end, v.depth, min_len);
+    else traverse_plain(X, P, prefix, v.start, v.end, v.depth, min_len);
+}
+
+// collectAllMEMs  sparseSA.cpp:873-899.  Counts (and with EMIT writes) the matches of one findMEM prefix.
+template <bool EMIT, class PAT>
+__device__ int collect_mem(const DIdx& X, const PAT& P, int prefix, IvalD mli, IvalD xmi, int min_len, int maxLeft, alfa_match* o) {
+    int cnt = 0;
+    auto one = [&](int i, int depth) {
+        int64_t mr; int mq, ml;
+        if (lmax_strict(X, P, prefix, (int64_t)X.SA[i], depth, min_len, maxLeft, mr, mq, ml)) {
+            if (EMIT) { alfa_match m; m.ref = mr; m.query = mq; m.len = ml; o[cnt] = m; }
+            ++cnt;
+        }
+    };
+    const int n = X.n;
+    const int xe = xmi.end;
+    for (int i = xmi.start; i <= xe; ++i) one(i, xmi.depth);
+    if (mli.start == xmi.start && mli.end == xmi.end) return cnt;
+    while (xmi.depth >= mli.depth) {
+        if (xmi.end + 1 < n) xmi.depth = max(d_lcp(X, xmi.start), d_lcp(X, xmi.end + 1));
+        else xmi.depth = d_lcp(X, xmi.start);
+        if (xmi.depth >= mli.depth) {
+            while (xmi.start > 0 && d_lcp(X, xmi.start) >= xmi.depth) { --xmi.start; one(xmi.start, xmi.depth); }
+            while (xmi.end + 1 < n && d_lcp(X, xmi.end + 1) >= xmi.depth) { ++xmi.end; one(xmi.end, xmi.depth); }
+        }
+    }
+    return cnt;
+}
+
+// collectXmiAndMli  sparseSA.cpp:910-966
+template <bool EMIT, class PAT>
+__device__ int collect_xmi_mli(const DIdx& X, const PAT& P, int prefix, IvalD mli, IvalD xmi, bool calcMli, int nextEndStop,
+                               int nextEndStopPrefix, int min_len, int maxCount, int maxLeft, alfa_match* o) {
+    int cnt = 0;
+    auto one = [&](int i, int depth) {
+        int64_t mr; int mq, ml;
+        if (lmax_strict(X, P, prefix, (int64_t)X.SA[i], depth, min_len, maxLeft, mr, mq, ml)) {
+            if (EMIT) { alfa_match m; m.ref = mr; m.query = mq; m.len = ml; o[cnt] = m; }
+            ++cnt;
+        }
+    };
+    const int64_t n = X.n;
+    const int K = X.K;
+    if (xmi.depth + prefix < min_len) return 0;
+    for (int i = xmi.start; i <= xmi.end; ++i) one(i, xmi.depth);
+    if (!calcMli || (mli.start == xmi.start && mli.end == xmi.end)) return cnt;
+    int64_t xs = xmi.start, xe = xmi.end;
+    int xd;
+    auto redepth = [&]() {
+        if (xe + 1 < n) xd = max(d_lcp(X, (int)xs), d_lcp(X, (int)xe + 1));
+        else xd = d_lcp(X, (int)xs);
+    };
+    redepth();
+    while ((xe - xs + 1) < maxCount && prefix + xd > nextEndStop && xd >= mli.depth && xd + prefix >= min_len) {
+        const int64_t prevStart = xs, prevStop = xe;
+        const int64_t room = (int64_t)maxCount - (xe - xs + 1);
+        const int64_t minStart = max((int64_t)0, xs - room);
+        while (xs >= minStart && xs > 0 && d_lcp(X, (int)xs) >= xd) --xs;
+        const int64_t maxEnd = min(n, xe + 1 + room);
+        while (xe + 1 < maxEnd && d_lcp(X, (int)xe + 1) >= xd) ++xe;
+        if ((xe - xs + 1) < maxCount) {
+            for (int64_t i = xs; i < prevStart; ++i) one((int)i, xd);
+            for (int64_t i = prevStop + 1; i <= xe; ++i) one((int)i, xd);
+            redepth();
+        }
+    }
+    if ((xe - xs + 1) < maxCount && prefix + xd == nextEndStop && xd >= mli.depth && xd + prefix >= min_len &&
+        prefix <= nextEndStopPrefix + K) {
+        const int64_t prevStart = xs, prevStop = xe;
+        const int64_t room = (int64_t)maxCount - (xe - xs + 1);
+        const int64_t minStart = max((int64_t)0, xs - room);
+        while (xs >= minStart && xs > 0 && d_lcp(X, (int)xs) >= xd) --xs;
+        const int64_t maxEnd = min(n, xe + room);
+        while (xe + 1 < maxEnd && d_lcp(X, (int)xe + 1) >= xd) ++xe;
+        if ((xe - xs + 1) < maxCount) {
+            for (int64_t i = xs; i < prevStart; ++i) one((int)i, xd);
+            for (int64_t i = prevStop + 1; i <= xe; ++i) one((int)i, xd);
+        }
+    }
+    return cnt;
+}
+
 // flat reference-order index t -> (phase k, step jj) of findSMAM's double loop
 struct PrefixMap {
     int step, nh, kh, Lmax;
@@ -240,7 +398,8 @@ __global__ __launch_bounds__(SEED_BLOCK) void smam_count_kernel(DIdx X, const Se
         int cnt = 0, start = 0, end = X.n - 1, depth = 0, prefix = 0;
         if (t < Q.npref) {
             prefix = pm.prefix_of(t);
-            traverse_child(X, P, prefix, start, end, depth, Q.plen);
+            if (X.has_child) traverse_child(X, P, prefix, start, end, depth, Q.plen);
+            else traverse_plain(X, P, prefix, start, end, depth, Q.plen);
             if (depth > 1 && depth >= min_lenK && (end - start + 1) <= maxCount) {
                 for (int i = start; i <= end; ++i) {
                     int64_t mr; int mq, ml;
@@ -294,6 +453,239 @@ __global__ void smam_emit_kernel(DIdx X, const SeedQ* __restrict__ qs, const uin
     }
 }
 
+// ---------------------------------------------------------------- MEM: traverse + count
+__global__ __launch_bounds__(SEED_BLOCK) void mem_count_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
+                                                              int64_t* __restrict__ read_total, WorkRec2* __restrict__ work,
+                                                              int* __restrict__ work_count, int work_cap, int lds_p) {
+    extern __shared__ uint8_t smem[];
+    __shared__ int sh_scan[SEED_BLOCK / 64];
+    const int r = blockIdx.x;
+    const SeedQ Q = qs[r];
+    const int tid = threadIdx.x;
+    PatD P;
+    P.len = Q.plen;
+    if (lds_p) {
+        for (int i = tid; i < Q.plen; i += SEED_BLOCK) smem[i] = reads[Q.poff + i];
+        __syncthreads();
+        P.p = smem;
+    } else {
+        P.p = reads + Q.poff;
+    }
+    const int K = X.K;
+    const int step = Q.sparse_q * K;
+    const int min_lenK = Q.min_len - (step - 1);
+    PrefixMap pm;
+    pm.step = step;
+    pm.Lmax = Q.plen - min_lenK;
+    pm.nh = pm.Lmax >= 0 ? pm.Lmax / step + 1 : 0;
+    {
+        const int kk = K < pm.Lmax + 1 ? K : pm.Lmax + 1;
+        const int r0 = pm.Lmax >= 0 ? pm.Lmax % step : 0;
+        pm.kh = kk < r0 + 1 ? kk : r0 + 1;
+    }
+    int running = 0;
+    for (int base = 0; base < Q.npref; base += SEED_BLOCK) {
+        const int t = base + tid;
+        int cnt = 0, prefix = 0;
+        IvalD mli = {0, X.n - 1, 0}, xmi = {0, X.n - 1, 0};
+        if (t < Q.npref) {
+            prefix = pm.prefix_of(t);
+            traverse_any(X, P, prefix, mli, min_lenK);                    // findMEM :1006
+            if (mli.depth > 1 && mli.depth >= min_lenK) {
+                xmi = mli;
+                traverse_any(X, P, prefix, xmi, Q.plen);                  // :1017
+                cnt = collect_mem<false>(X, P, prefix, mli, xmi, Q.min_len, step, nullptr);
+            }
+        }
+        int total;
+        const int excl = block_excl_scan(cnt, sh_scan, total);
+        if (cnt > 0) {
+            const int slot = atomicAdd(work_count, 1);
+            if (slot < work_cap) {
+                WorkRec2 w;
+                w.read = r; w.woff = running + excl; w.prefix = prefix;
+                w.ms = mli.start; w.me = mli.end; w.md = mli.depth; w.xs = xmi.start; w.xe = xmi.end; w.xd = xmi.depth;
+                w.calc = 0; w.nes = 0; w.nesp = 0;
+                work[slot] = w;
+            }
+        }
+        running += total;
+    }
+    if (tid == 0) read_total[r] = running;
+}
+
+// ---------------------------------------------------------------- SMEM: traverse, per-read selection, count
+// Per-read tables (ints, each `W = plen + 2` wide), in LDS when they fit, else in the global scratch at Q.soff:
+constexpr int SMEM_TABLES = 14;
+enum { T_MS, T_ME, T_MD, T_XS, T_XE, T_XD, T_ORD, T_SEL, T_NES, T_NESP, T_BL, T_SC, T_PB, T_CS };
+
+__global__ __launch_bounds__(SEED_BLOCK) void smem_count_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
+                                                               int64_t* __restrict__ read_total, WorkRec2* __restrict__ work,
+                                                               int* __restrict__ work_count, int work_cap, int lds_p, int lds_tab,
+                                                               int* g_scratch) {
+    extern __shared__ uint8_t smem[];
+    __shared__ int sh_scan[SEED_BLOCK / 64];
+    __shared__ int sh_nt;
+    const int r = blockIdx.x;
+    const SeedQ Q = qs[r];
+    const int tid = threadIdx.x;
+    PatD P;
+    P.len = Q.plen;
+    const int pbytes = (Q.plen + 15) & ~15;
+    if (lds_p) {
+        for (int i = tid; i < Q.plen; i += SEED_BLOCK) smem[i] = reads[Q.poff + i];
+        P.p = smem;
+    } else {
+        P.p = reads + Q.poff;
+    }
+    const int W = (Q.plen > Q.npref ? Q.plen : Q.npref) + 2;
+    int* tab = lds_tab ? (int*)(smem + (lds_p ? pbytes : 0)) : g_scratch + Q.soff;
+    const int K = X.K;
+    const int sparseQ = Q.sparse_q;
+    const int step = sparseQ * K;
+    const int min_lenK = Q.min_len - (step - 1);
+    const int minMin_len = sparseQ > 1 ? Q.min_len - K : Q.min_len;
+    // candidate prefixes are 0 .. plen - min_lenK (sparseSA.cpp:1140); Q.npref counts them
+    const int np = Q.npref;                                  // == Lmax + 1 (0 when the call is a no-op)
+    __syncthreads();
+    // stage 1: mli of every candidate prefix
+    for (int p = tid; p < np; p += SEED_BLOCK) {
+        IvalD mli = {0, X.n - 1, 0};
+        traverse_child(X, P, p, mli.start, mli.end, mli.depth, min_lenK);
+        tab[T_MS * W + p] = mli.start; tab[T_ME * W + p] = mli.end; tab[T_MD * W + p] = mli.depth;
+        tab[T_XD * W + p] = sparseQ > 1 ? -1 : -2;
+    }
+    __syncthreads();
+    // the reference's prefix loop skips (sparseQ-1)*K positions after a prefix == K-1 (mod K) -- but only when that prefix
+    // matched deeper than one character (the `continue` at :1146 bypasses the skip), so the visited set depends on the data
+    if (sparseQ > 1 && tid == 0) {
+        for (int p = 0; p < np; ++p) {
+            tab[T_XD * W + p] = -2;
+            if (tab[T_MD * W + p] <= 1) continue;
+            if (p % K == K - 1) p += (sparseQ - 1) * K;
+        }
+    }
+    __syncthreads();
+    // stage 2: xmi of every visited prefix whose mli reached min_lenK
+    for (int p = tid; p < np; p += SEED_BLOCK) {
+        const int md = tab[T_MD * W + p];
+        int xd = -1;
+        if (tab[T_XD * W + p] == -2 && md > 1 && md >= min_lenK) {
+            IvalD xmi = {tab[T_MS * W + p], tab[T_ME * W + p], md};
+            traverse_child(X, P, p, xmi.start, xmi.end, xmi.depth, Q.plen);
+            if (xmi.depth + p >= Q.min_len) { tab[T_XS * W + p] = xmi.start; tab[T_XE * W + p] = xmi.end; xd = xmi.depth; }
+        }
+        tab[T_XD * W + p] = xd;
+    }
+    for (int e = tid; e < W; e += SEED_BLOCK) { tab[T_BL * W + e] = -1; tab[T_SC * W + e] = -1; tab[T_CS * W + e] = 0; }
+    __syncthreads();
+    // per-read selection (sparseSA.cpp:1160-1207) on one lane: counting sort by end position (descending; prefixes stay
+    // ascending inside a group = compIntervTupleRev :52-54), then the two sweeps over the groups
+    if (tid == 0) {
+        int* ord = tab + T_ORD * W; int* sel = tab + T_SEL * W; int* nes = tab + T_NES * W; int* nesp = tab + T_NESP * W;
+        int* bl = tab + T_BL * W; int* sc = tab + T_SC * W; int* pb = tab + T_PB * W; int* cs = tab + T_CS * W;
+        const int* xd = tab + T_XD * W; const int* xs = tab + T_XS * W; const int* xe = tab + T_XE * W;
+        const int plen = Q.plen;
+        int nt = 0;
+        for (int p = 0; p < np; ++p) if (xd[p] >= 0) { cs[p + xd[p]]++; ++nt; }      // end position <= plen
+        int pos = 0;
+        for (int e = plen; e >= 0; --e) { const int c = cs[e]; cs[e] = pos; pos += c; }
+        for (int p = 0; p < np; ++p) if (xd[p] >= 0) ord[cs[p + xd[p]]++] = p;
+        // first sweep: beginLong / smemCount
+        int i = 0;
+        while (i < nt) {
+            int64_t curSize = 0;
+            const int curEnd = ord[i] + xd[ord[i]];
+            bool foundMax = false;
+            while (i < nt && ord[i] + xd[ord[i]] == curEnd) {
+                const int p = ord[i];
+                if (!foundMax || p <= bl[curEnd] + K) curSize += (int64_t)xe[p] - xs[p] + 1;
+                if (!foundMax && curSize >= Q.max_smem) { bl[curEnd] = p; foundMax = true; }
+                ++i;
+            }
+            sc[curEnd] = (int)curSize;
+        }
+        // pb[e] = largest e' <= e with smemCount[e'] >= max_smem_cont (the nextEndStop search :1190-1192)
+        int last = -1;
+        for (int e = 0; e <= plen; ++e) { if (sc[e] >= Q.max_smem) last = e; pb[e] = last; }
+        // second sweep: which tuples are expanded, and with which parameters
+        i = 0;
+        int curMinPos = plen;
+        while (i < nt) {
+            const int curEnd = ord[i] + xd[ord[i]];
+            const bool skipEnd = sc[curEnd] >= Q.max_count || ord[i] > curMinPos + K;
+            if (!skipEnd && sc[curEnd] >= Q.max_smem) curMinPos = min(curMinPos, bl[curEnd]);
+            while (i < nt && ord[i] + xd[ord[i]] == curEnd) {
+                const int p = ord[i];
+                int s = 0;
+                if (!skipEnd && p <= curMinPos + K && (sc[curEnd] < Q.max_smem || p <= bl[curEnd] + K)) {
+                    if (sc[curEnd] >= Q.max_smem) { s = 1; nes[p] = 0; nesp[p] = 0; }
+                    else {
+                        const int stop = curEnd >= 1 ? pb[curEnd - 1] : -1;
+                        s = 2; nes[p] = stop; nesp[p] = stop >= 0 ? bl[stop] : curEnd;
+                    }
+                }
+                sel[p] = s;
+                ++i;
+            }
+        }
+        sh_nt = nt;
+    }
+    __syncthreads();
+    // stage 3: count what every selected tuple emits, in the sorted order
+    const int nt = sh_nt;
+    int running = 0;
+    for (int base = 0; base < nt; base += SEED_BLOCK) {
+        const int j = base + tid;
+        int cnt = 0, p = 0, s = 0;
+        IvalD mli = {0, 0, 0}, xmi = {0, 0, 0};
+        if (j < nt) {
+            p = tab[T_ORD * W + j];
+            s = tab[T_SEL * W + p];
+            if (s) {
+                mli = {tab[T_MS * W + p], tab[T_ME * W + p], tab[T_MD * W + p]};
+                xmi = {tab[T_XS * W + p], tab[T_XE * W + p], tab[T_XD * W + p]};
+                cnt = collect_xmi_mli<false>(X, P, p, mli, xmi, s == 2, tab[T_NES * W + p], tab[T_NESP * W + p], minMin_len, Q.max_count,
+                                             step, nullptr);
+            }
+        }
+        int total;
+        const int excl = block_excl_scan(cnt, sh_scan, total);
+        if (cnt > 0) {
+            const int slot = atomicAdd(work_count, 1);
+            if (slot < work_cap) {
+                WorkRec2 w;
+                w.read = r; w.woff = running + excl; w.prefix = p;
+                w.ms = mli.start; w.me = mli.end; w.md = mli.depth; w.xs = xmi.start; w.xe = xmi.end; w.xd = xmi.depth;
+                w.calc = s == 2; w.nes = tab[T_NES * W + p]; w.nesp = tab[T_NESP * W + p];
+                work[slot] = w;
+            }
+        }
+        running += total;
+    }
+    if (tid == 0) read_total[r] = running;
+}
+
+// ---------------------------------------------------------------- MEM / SMEM: emit
+template <int TYPE>
+__global__ void emit2_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads, const int64_t* __restrict__ read_base,
+                             int nq, const WorkRec2* __restrict__ work, const int* __restrict__ work_count, int work_cap,
+                             alfa_match* __restrict__ out, int64_t out_cap) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nwork = *work_count;
+    if (nwork > work_cap || read_base[nq] > out_cap || g >= nwork) return;
+    const WorkRec2 w = work[g];
+    const SeedQ Q = qs[w.read];
+    PatG P; P.p = reads + Q.poff; P.len = Q.plen;
+    const int K = X.K;
+    const int step = Q.sparse_q * K;
+    alfa_match* o = out + read_base[w.read] + w.woff;
+    const IvalD mli = {w.ms, w.me, w.md}, xmi = {w.xs, w.xe, w.xd};
+    if (TYPE == ALFA_SEED_MEM) collect_mem<true>(X, P, w.prefix, mli, xmi, Q.min_len, step, o);
+    else collect_xmi_mli<true>(X, P, w.prefix, mli, xmi, w.calc != 0, w.nes, w.nesp, Q.sparse_q > 1 ? Q.min_len - K : Q.min_len,
+                               Q.max_count, step, o);
+}
+
 // number of prefix queries of one SMAM call (mirrors findSMAM's loop bounds, sparseSA.cpp:1066-1072)
 int64_t count_prefixes(int64_t K, int plen, int min_len, int sparse_q) {
     if (min_len < K) return 0;                       // sparseSA.cpp:1122
@@ -304,6 +696,13 @@ int64_t count_prefixes(int64_t K, int plen, int min_len, int sparse_q) {
     int64_t tot = 0;
     for (int64_t k = 0; k < K && k <= L; ++k) tot += (L - k) / step + 1;
     return tot;
+}
+
+// candidate prefixes of one SMEM call: 0 .. |P| - min_lenK (sparseSA.cpp:1128,1140)
+int64_t count_prefixes_smem(int64_t K, int plen, int min_len, int sparse_q) {
+    if (min_len < K) return 0;
+    const int64_t min_lenK = min_len - ((int64_t)sparse_q * K - 1);
+    return std::max<int64_t>(0, (int64_t)plen - min_lenK + 1);
 }
 
 int upload(alfa::DevBuf& b, const void* src, size_t bytes, size_t pad = 0) {
@@ -359,8 +758,12 @@ struct alfa_seed_plan {
     size_t read_bytes = 0;
     int work_cap = 0;
     int64_t out_cap = 0;
-    alfa::DevBuf d_reads, d_q, d_tot, d_base, d_work, d_out, d_tmp;
+    alfa::DevBuf d_reads, d_q, d_tot, d_base, d_work, d_out, d_tmp, d_scr;
     size_t tmp_bytes = 0;
+    int mem_type = ALFA_SEED_SMAM;
+    size_t work_rec = sizeof(WorkRec);
+    int max_w = 0;          // SMEM: widest per-read table
+    bool lds_tab = true;    // SMEM: tables fit in LDS
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool launched = false;
 };
@@ -372,16 +775,18 @@ DIdx make_didx(const alfa_index* ix) {
     X.S = ix->S.as<uint8_t>(); X.SA = ix->SA.as<uint32_t>(); X.LCP = ix->LCP.as<uint8_t>();
     X.Midx = ix->Midx.as<int64_t>(); X.Mval = ix->Mval.as<int32_t>(); X.CHILD = ix->CHILD.as<int32_t>();
     X.KMR = ix->KMR.as<uint2>();
-    X.N = ix->N; X.n = (int32_t)ix->n; X.nM = (int32_t)ix->nM; X.K = (int32_t)ix->K; X.has_kmer = ix->has_kmer;
+    X.N = ix->N; X.n = (int32_t)ix->n; X.nM = (int32_t)ix->nM; X.K = (int32_t)ix->K; X.has_kmer = ix->has_kmer; X.has_child = ix->has_child;
     return X;
 }
 
 int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, const alfa_seed_query* q, int nq) {
-    if (mem_type != ALFA_SEED_SMAM)
-        return alfa::fail(ALFA_ENOTSUP, "only ALFA_SEED_SMAM (the reference's default seed type) has a HIP kernel so far");
-    if (!ix->has_child) return alfa::fail(ALFA_ENOTSUP, "the HIP seed kernels need an index with a child table (--no-child unsupported)");
+    if (mem_type != ALFA_SEED_SMAM && mem_type != ALFA_SEED_MEM && mem_type != ALFA_SEED_SMEM)
+        return alfa::fail(ALFA_ENOTSUP, "seed type has no HIP kernel (SMAM, MEM and SMEM do; SMEMP is unreachable from the reference's CLI)");
+    if (!ix->has_child && mem_type == ALFA_SEED_SMEM)
+        return alfa::fail(ALFA_ENOTSUP, "SMEM needs an index with a child table (the reference calls traverse_faster unconditionally)");
     if (ix->has_suflink) return alfa::fail(ALFA_ENOTSUP, "suffix-link (--suflink) indexes are not supported by the HIP seed kernels");
-    pl->ix = ix; pl->nq = nq; pl->launched = false;
+    pl->ix = ix; pl->nq = nq; pl->launched = false; pl->mem_type = mem_type;
+    pl->work_rec = mem_type == ALFA_SEED_SMAM ? sizeof(WorkRec) : sizeof(WorkRec2);
     if (!pl->ev0) { ALFA_HIP(hipEventCreate(&pl->ev0)); ALFA_HIP(hipEventCreate(&pl->ev1)); }
     size_t bytes = 0;
     int max_plen = 0;
@@ -401,25 +806,37 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
     uint8_t* hp = cx->h_in.as<uint8_t>();
     SeedQ* hq = cx->h_tasks.as<SeedQ>();
     size_t po = 0;
-    int64_t total_pref = 0;
+    int64_t total_pref = 0, scr_ints = 0;
+    int max_w = 0;
     for (int i = 0; i < nq; ++i) {
         SeedQ& s = hq[i];
         s.poff = (int64_t)po;
         s.plen = q[i].plen; s.min_len = q[i].min_len; s.max_count = q[i].max_count; s.sparse_q = q[i].sparse_q;
-        const int64_t np = count_prefixes(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q);
-        if (np < 0 || np > 0x7fffffff) return alfa::fail(ALFA_EINVAL, "seed query has too many prefixes");
+        const int64_t np = mem_type == ALFA_SEED_SMEM ? count_prefixes_smem(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q)
+                                                      : count_prefixes(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q);
+        if (np < 0 || np > 0x3fffffff) return alfa::fail(ALFA_EINVAL, "seed query has too many prefixes");
         s.npref = (int32_t)np;
-        s.pad = 0;
+        s.max_smem = q[i].max_smem_cont;
+        s.soff = scr_ints;
+        const int w = (int)std::max<int64_t>(q[i].plen, np) + 2;
+        max_w = std::max(max_w, w);
+        if (mem_type == ALFA_SEED_SMEM) scr_ints += (int64_t)SMEM_TABLES * w;
         total_pref += np;
         if (q[i].plen) memcpy(hp + po, q[i].P, (size_t)q[i].plen);
         po += (size_t)q[i].plen;
     }
     pl->total_pref = total_pref;
+    pl->max_w = max_w;
+    if (mem_type == ALFA_SEED_SMEM) {
+        const size_t pbytes = max_plen <= 48 * 1024 ? (((size_t)max_plen + 15) & ~(size_t)15) : 0;
+        pl->lds_tab = pbytes + (size_t)SMEM_TABLES * 4 * (size_t)max_w + 64 <= 60 * 1024;
+        if (!pl->lds_tab && (rc = pl->d_scr.reserve(4 * (size_t)scr_ints + 64))) return rc;
+    }
     pl->work_cap = (int)std::min<int64_t>(std::max<int64_t>(4096, 4 * (int64_t)nq), std::max<int64_t>(total_pref, 1));
     pl->out_cap = std::max<int64_t>(4096, 16 * (int64_t)nq);
     pl->tmp_bytes = 0;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, pl->tmp_bytes, pl->d_tot.as<int64_t>(), pl->d_base.as<int64_t>(), nq + 1, cx->stream));
-    if ((rc = pl->d_work.reserve(sizeof(WorkRec) * (size_t)pl->work_cap + 64)) ||
+    if ((rc = pl->d_work.reserve(pl->work_rec * (size_t)pl->work_cap + 64)) ||
         (rc = pl->d_out.reserve(sizeof(alfa_match) * (size_t)pl->out_cap)) || (rc = pl->d_tmp.reserve(pl->tmp_bytes + 64)))
         return rc;
     ALFA_HIP(hipMemcpyAsync(pl->d_reads.p, hp, bytes, hipMemcpyHostToDevice, cx->stream));
@@ -436,20 +853,40 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
     const int nq = pl->nq;
     const int lds_p = pl->max_plen <= 48 * 1024;
     const size_t lds_bytes = lds_p ? (size_t)pl->max_plen + 16 : 0;
-    int* d_wc = (int*)((char*)pl->d_work.p + sizeof(WorkRec) * (size_t)pl->work_cap);
+    int* d_wc = (int*)((char*)pl->d_work.p + pl->work_rec * (size_t)pl->work_cap);
     int64_t* d_tot = pl->d_tot.as<int64_t>();
     int64_t* d_base = pl->d_base.as<int64_t>();
+    const SeedQ* d_q = pl->d_q.as<SeedQ>();
+    const uint8_t* d_reads = pl->d_reads.as<uint8_t>();
     ALFA_HIP(hipMemsetAsync(d_wc, 0, 4, st));
     ALFA_HIP(hipMemsetAsync(d_tot + nq, 0, 8, st));
     ALFA_HIP(hipEventRecord(pl->ev0, st));
-    hipLaunchKernelGGL(smam_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, pl->d_q.as<SeedQ>(), pl->d_reads.as<uint8_t>(), d_tot,
-                       pl->d_work.as<WorkRec>(), d_wc, pl->work_cap, lds_p);
+    if (pl->mem_type == ALFA_SEED_SMAM) {
+        hipLaunchKernelGGL(smam_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec>(), d_wc,
+                           pl->work_cap, lds_p);
+    } else if (pl->mem_type == ALFA_SEED_MEM) {
+        hipLaunchKernelGGL(mem_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec2>(), d_wc,
+                           pl->work_cap, lds_p);
+    } else {
+        const size_t pbytes = lds_p ? (((size_t)pl->max_plen + 15) & ~(size_t)15) : 0;
+        const size_t lds2 = pbytes + (pl->lds_tab ? (size_t)SMEM_TABLES * 4 * (size_t)pl->max_w : 0) + 16;
+        hipLaunchKernelGGL(smem_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds2, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec2>(), d_wc,
+                           pl->work_cap, lds_p, pl->lds_tab ? 1 : 0, pl->d_scr.as<int>());
+    }
     ALFA_HIP(hipGetLastError());
     ALFA_HIP(hipEventRecord(pl->ev1, st));
     size_t tb = pl->tmp_bytes;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_tmp.p, tb, d_tot, d_base, nq + 1, st));
-    hipLaunchKernelGGL(smam_emit_kernel, dim3((pl->work_cap + 127) / 128), dim3(128), 0, st, X, pl->d_q.as<SeedQ>(), pl->d_reads.as<uint8_t>(),
-                       d_base, nq, pl->d_work.as<WorkRec>(), d_wc, pl->work_cap, pl->d_out.as<alfa_match>(), pl->out_cap);
+    const dim3 eg((pl->work_cap + 127) / 128), eb(128);
+    if (pl->mem_type == ALFA_SEED_SMAM)
+        hipLaunchKernelGGL(smam_emit_kernel, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec>(), d_wc, pl->work_cap,
+                           pl->d_out.as<alfa_match>(), pl->out_cap);
+    else if (pl->mem_type == ALFA_SEED_MEM)
+        hipLaunchKernelGGL(emit2_kernel<ALFA_SEED_MEM>, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec2>(), d_wc, pl->work_cap,
+                           pl->d_out.as<alfa_match>(), pl->out_cap);
+    else
+        hipLaunchKernelGGL(emit2_kernel<ALFA_SEED_SMEM>, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec2>(), d_wc, pl->work_cap,
+                           pl->d_out.as<alfa_match>(), pl->out_cap);
     ALFA_HIP(hipGetLastError());
     return ALFA_OK;
 }
@@ -463,7 +900,7 @@ int plan_fetch(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_match** matches, int64_t*
     int rc;
     for (int attempt = 0;; ++attempt) {
         int nwork = 0;
-        int* d_wc = (int*)((char*)pl->d_work.p + sizeof(WorkRec) * (size_t)pl->work_cap);
+        int* d_wc = (int*)((char*)pl->d_work.p + pl->work_rec * (size_t)pl->work_cap);
         ALFA_HIP(hipMemcpyAsync(&nwork, d_wc, 4, hipMemcpyDeviceToHost, st));
         ALFA_HIP(hipMemcpyAsync(offsets, pl->d_base.p, 8 * ((size_t)nq + 1), hipMemcpyDeviceToHost, st));
         ALFA_HIP(hipStreamSynchronize(st));
@@ -473,7 +910,7 @@ int plan_fetch(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_match** matches, int64_t*
         // grow to the exact need reported by the device and run again
         if (nwork > pl->work_cap) {
             pl->work_cap = nwork;
-            if ((rc = pl->d_work.reserve(sizeof(WorkRec) * (size_t)pl->work_cap + 64))) return rc;
+            if ((rc = pl->d_work.reserve(pl->work_rec * (size_t)pl->work_cap + 64))) return rc;
         }
         if (total > pl->out_cap) {
             pl->out_cap = total;
@@ -495,7 +932,7 @@ int plan_fetch(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_match** matches, int64_t*
 
 void plan_release(alfa_seed_plan* pl) {
     pl->d_reads.release(); pl->d_q.release(); pl->d_tot.release(); pl->d_base.release(); pl->d_work.release(); pl->d_out.release();
-    pl->d_tmp.release();
+    pl->d_tmp.release(); pl->d_scr.release();
     if (pl->ev0) { (void)hipEventDestroy(pl->ev0); (void)hipEventDestroy(pl->ev1); pl->ev0 = pl->ev1 = nullptr; }
 }
 

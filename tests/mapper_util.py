@@ -27,7 +27,6 @@ CONFIGS = {
     "454_s12_e12": (12, ["-0", "454reads.fq", "-e", "0.12"]),
     "454_s1_a5": (1, ["-0", "454reads.fq", "-a", "5"]),
 }
-SMAM_CONFIGS = [k for k in CONFIGS if "mem" not in k]      # seed types with a HIP kernel
 
 
 def workdir():

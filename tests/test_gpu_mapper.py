@@ -13,20 +13,10 @@ import seqgen
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", M.SMAM_CONFIGS)
+@pytest.mark.parametrize("name", list(M.CONFIGS))
 def test_gpu_mapper_matches_reference_sam(gpu, name):
     body = M.run_config(M.GPU_EXE, name, ["-t", "2"])
     assert M.md5(body) == M.golden_md5(name)
-
-
-def test_gpu_mapper_unsupported_seed_type_fails_loudly(gpu):
-    d = M.workdir()
-    pre = os.path.join(d, "idx_alfalfa_amd_12")
-    if not os.path.exists(pre + ".aux"):
-        subprocess.run([M.GPU_EXE, "index", "-r", "reference.fasta", "-p", pre, "-s", "12"], cwd=d, check=True)
-    p = subprocess.run([M.GPU_EXE, "align", "-i", pre, "-0", "454reads.fq", "--seed", "MEM", "-o", os.path.join(d, "x.sam")], cwd=d,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert p.returncode != 0 and b"HIP kernel" in p.stderr
 
 
 def test_gpu_mapper_vs_oracle_mapper_synthetic(gpu):
@@ -51,7 +41,8 @@ def test_gpu_mapper_vs_oracle_mapper_synthetic(gpu):
     fq("long.fq", seqgen.sim_reads(rng, cat, 300, 2000, 8000, 0.10))
     subprocess.run([M.GPU_EXE, "index", "-r", "syn.fa", "-p", "syn12", "-s", "12"], cwd=d, check=True, stdout=subprocess.DEVNULL,
                    stderr=subprocess.DEVNULL)
-    for tag, args in (("short", ["-0", "short.fq"]), ("long", ["-0", "long.fq", "-e", "0.12"]), ("longdef", ["-0", "long.fq"])):
+    for tag, args in (("short", ["-0", "short.fq"]), ("long", ["-0", "long.fq", "-e", "0.12"]), ("longdef", ["-0", "long.fq"]),
+                      ("short_mem", ["-0", "short.fq", "--seed", "MEM"]), ("long_psmem", ["-0", "long.fq", "-e", "0.12", "--seed", "PSMEM"])):
         outs = []
         for exe, thr in ((M.GPU_EXE, "4"), (M.CPU_EXE, "16")):
             out = os.path.join(d, "syn_%s_%s.sam" % (tag, os.path.basename(exe)))

@@ -1,4 +1,4 @@
-"""GPU parity: the HIP SMAM seed kernels (through the C ABI) vs the CPU oracle, bit-exact and in order."""
+"""GPU parity: the HIP seed kernels (SMAM, MEM, SMEM; through the C ABI) vs the CPU oracle, bit-exact and in order."""
 import numpy as np
 import pytest
 
@@ -9,10 +9,10 @@ import seqgen
 pytestmark = pytest.mark.gpu
 
 
-def _check(hidx, didx, reads, min_len, max_count, sq):
-    q = ffi.make_seed_queries(reads, min_len, max_count, sq)
-    mg, og = didx.seed_batch(ffi.SEED_SMAM, q)
-    mc, oc = O.orc_seed_batch(hidx.view, ffi.SEED_SMAM, q)
+def _check(hidx, didx, reads, min_len, max_count, sq, mt=ffi.SEED_SMAM, max_smem=10):
+    q = ffi.make_seed_queries(reads, min_len, max_count, sq, max_smem)
+    mg, og = didx.seed_batch(mt, q)
+    mc, oc = O.orc_seed_batch(hidx.view, mt, q)
     assert np.array_equal(og, oc), "per-read offsets differ"
     assert np.array_equal(mg, mc), "matches differ"
     return len(mg)
@@ -72,6 +72,64 @@ def test_smam_index_without_kmer_table(gpu):
     assert _check(hidx, didx, reads, 30, 1000, 2) > 50
 
 
+@pytest.mark.parametrize("mt", [ffi.SEED_MEM, ffi.SEED_SMEM])
+@pytest.mark.parametrize("K", [1, 3, 12])
+def test_mem_smem_random_ref(gpu, K, mt):
+    rng = np.random.default_rng(200 + K)
+    ref = seqgen.rand_ref(rng, 300000)
+    hidx = ffi.HostIndex.build_mem(["chr1"], [ref], K=K)
+    didx = ffi.DeviceIndex(hidx, gpu)
+    reads = seqgen.sim_reads(rng, ref, 300, 100, 400, 0.03)
+    reads += [b"", b"acgt", b"n" * 60, reads[0][:50] + b"n" + reads[0][50:]]
+    ml = [seqgen.seed_params(K, len(r))[0] for r in reads]
+    sq = [seqgen.seed_params(K, len(r))[1] for r in reads]
+    assert _check(hidx, didx, reads, ml, 10000, sq, mt) > 200
+    _check(hidx, didx, reads, max(20, K + 10), 100000, 1, mt)
+    _check(hidx, didx, reads, 25, 3, 1, mt, max_smem=2)
+    if K > 1:
+        _check(hidx, didx, reads, 50, 100, 3, mt, max_smem=1)     # sparseQ > 1: data-dependent prefix skipping in SMEM
+
+
+@pytest.mark.parametrize("mt", [ffi.SEED_MEM, ffi.SEED_SMEM])
+def test_mem_smem_repeats_multi_contig(gpu, mt):
+    rng = np.random.default_rng(14)
+    a = seqgen.rand_ref(rng, 50000)
+    b = seqgen.rand_ref(rng, 20000)
+    c = a[2000:6000] + b"n" * 20 + b[100:3100] + b"acgt" * 200 + a[2000:6000] + b"a" * 900
+    names, seqs = ["a", "b", "c"], [a, b, c]
+    for K in (1, 4, 12):
+        hidx = ffi.HostIndex.build_mem(names, seqs, K=K)
+        didx = ffi.DeviceIndex(hidx, gpu)
+        cat = b"a".join(seqs)
+        reads = seqgen.sim_reads(rng, cat, 200, 60, 900, 0.02)
+        reads += [b"acgt" * 60, b"a" * 300, c[3990:4300]]
+        assert _check(hidx, didx, reads, 40, 10000, seqgen.seed_params(K, 250)[1], mt) > 100
+        _check(hidx, didx, reads, 25, 50, 1, mt, max_smem=3)
+
+
+def test_smem_long_reads_use_global_tables(gpu):
+    rng = np.random.default_rng(13)
+    ref = seqgen.rand_ref(rng, 500000)
+    hidx = ffi.HostIndex.build_mem(["chr1"], [ref], K=12)
+    didx = ffi.DeviceIndex(hidx, gpu)
+    reads = seqgen.sim_reads(rng, ref, 30, 2000, 6000, 0.08)
+    ml = [seqgen.seed_params(12, len(r), 0.10)[0] for r in reads]
+    sq = [seqgen.seed_params(12, len(r), 0.10)[1] for r in reads]
+    for mt in (ffi.SEED_MEM, ffi.SEED_SMEM):
+        assert _check(hidx, didx, reads, ml, 10000, sq, mt) > 30
+
+
+@pytest.mark.parametrize("mt", [ffi.SEED_SMAM, ffi.SEED_MEM])
+def test_index_without_child_table(gpu, mt):
+    rng = np.random.default_rng(9)
+    ref = seqgen.rand_ref(rng, 80000)
+    for K, kmer in ((1, False), (4, False)):
+        hidx = ffi.HostIndex.build_mem(["x"], [ref], K=K, child=False, kmer=kmer)
+        didx = ffi.DeviceIndex(hidx, gpu)
+        reads = seqgen.sim_reads(rng, ref, 100, 60, 400, 0.03)
+        assert _check(hidx, didx, reads, 30, 1000, 1, mt) > 50
+
+
 def test_unsupported_types_fail_loudly(gpu):
     rng = np.random.default_rng(5)
     ref = seqgen.rand_ref(rng, 20000)
@@ -79,3 +137,7 @@ def test_unsupported_types_fail_loudly(gpu):
     didx = ffi.DeviceIndex(hidx, gpu)
     with pytest.raises(ffi.AlfaError):
         didx.seed_batch(ffi.SEED_SMAM, ffi.make_seed_queries([ref[:100]], 40, 100, 1))
+    hidx2 = ffi.HostIndex.build_mem(["x"], [ref], K=3)
+    didx2 = ffi.DeviceIndex(hidx2, gpu)
+    with pytest.raises(ffi.AlfaError):
+        didx2.seed_batch(ffi.SEED_SMEMP, ffi.make_seed_queries([ref[:100]], 40, 100, 1))
