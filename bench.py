@@ -116,6 +116,46 @@ def mapper_dp_tasks(workdir, index_prefix, reads, threads=8):
     return out
 
 
+# ---- multi-GPU plumbing (reads sharded over ranks, index replicated, no data-path collective)
+def rank_rng(rank):
+    """every rank simulates its own shard of reads"""
+    return np.random.default_rng(1000 + rank)
+
+
+def max_over_ranks(elapsed, world, device):
+    """the job's time is the slowest rank's"""
+    if world <= 1:
+        return elapsed
+    import torch
+    import torch.distributed as dist
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def whole_job_value(batch, steps, world, elapsed):
+    """reads all ranks processed / the slowest rank's time"""
+    return batch * steps * world / elapsed
+
+
+def dist_selftest(args, rank, world):
+    """CPU rehearsal of the N>1 control flow (tests/test_bench_dist.py, gloo): shard -> barrier -> MAX -> rank 0 reports"""
+    import zlib
+    import torch
+    import torch.distributed as dist
+    ref = make_reference(200000, 1)
+    fw, _, _, _ = simulate_batch(rank_rng(rank), ref, 64, 100, 0.02)
+    crc = zlib.crc32(b"".join(fw))
+    dist.barrier()
+    elapsed = max_over_ranks(0.25 * (rank + 1), world, "cpu")
+    sums = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sums, torch.tensor([crc], dtype=torch.int64))
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "elapsed": elapsed, "value": whole_job_value(64, args.steps, world, elapsed),
+                          "scaling": "weak", "shard_crc": [int(x.item()) for x in sums]}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +170,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20000)
     ap.add_argument("--e2e-reads", type=int, default=300000, help="reads for the end-to-end command line comparison (0 = skip)")
     ap.add_argument("--e2e-threads", type=int, default=16)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for --dist-selftest)")
+    ap.add_argument("--dist-selftest", action="store_true", help="CPU rehearsal of the multi-rank control flow, no GPU work")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,10 +179,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    if args.dist_selftest:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        return dist_selftest(args, rank, world)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     dev = local_rank if world > 1 else 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libalfa_hot has no CPU fallback")
@@ -166,7 +212,7 @@ def main():
     edit_dist = int(err_percent * args.read_len) + 1
     P = ffi.default_params()
     nsteps = args.warmup + args.steps
-    rng = np.random.default_rng(1000 + rank)
+    rng = rank_rng(rank)
     steps = []
     sample = None
     for s in range(nsteps):
@@ -207,10 +253,7 @@ def main():
     ffi.sync(dev)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(elapsed, world, "cuda")
 
     timed = steps[args.warmup:]
     seed_ms = [st[0].kernel_ms for st in timed]
@@ -303,11 +346,10 @@ def main():
         if "reference_cpu" in e2e and "alfalfa_amd_gpu" in e2e:
             e2e["sam_identical"] = e2e["reference_cpu"]["sam_md5"] == e2e["alfalfa_amd_gpu"]["sam_md5"]
 
-    total_reads = args.batch * args.steps * world
     dp_ms = sum(ext_ms) + sum(nw_ms) + sum(gl_ms)
     out = {
         "metric": "mapped reads/sec (hot path: SMAM seeds both strands + banded DP) + banded-DP GCUPS",
-        "value": total_reads / elapsed,
+        "value": whole_job_value(args.batch, args.steps, world, elapsed),
         "unit": "reads/s",
         "n_gpus": world,
         "steps": args.steps,
