@@ -27,6 +27,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -36,7 +37,7 @@ struct alfa_index {
     int device = 0;
     int64_t N = 0, n = 0, K = 1, logN = 0, NKm1 = 0, nM = 0;
     int has_child = 0, has_suflink = 0, has_kmer = 0;
-    alfa::DevBuf S, SA, LCP, Midx, Mval, CHILD, KMR;
+    alfa::DevBuf S, SA, LCP, Midx, Mval, CHILD, KMR, KMR2, KBIT;
 };
 
 namespace {
@@ -52,7 +53,9 @@ struct DIdx {
     const int64_t* __restrict__ Midx;
     const int32_t* __restrict__ Mval;
     const int32_t* __restrict__ CHILD;
-    const uint2* __restrict__ KMR;
+    const uint2* __restrict__ KMR;      // the reference's 10-mer table {left, right}
+    const uint4* __restrict__ KMR2;     // derived at upload: {left, right, SA[left], S[SA[left]+10..+13]}: a single-suffix hit needs no SA / S probe
+    const uint32_t* __restrict__ KBIT;  // derived at upload: bit per 10-mer, set when right > 0 (128 KiB: stays in L2)
     int64_t N;
     int32_t n, nM, K, has_kmer, has_child;
 };
@@ -101,90 +104,165 @@ __device__ __forceinline__ int d_lcp(const DIdx& X, int i) {
 
 __device__ __forceinline__ uint32_t d_s(const DIdx& X, int64_t pos) { return (pos >= 0 && pos < X.N + 16) ? X.S[pos] : 0u; }
 
+// 8 bytes from any byte address (gfx950 runs in unaligned access mode: one global_load_dwordx2 / ds_read_b64)
+__device__ __forceinline__ uint64_t ld8(const uint8_t* p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// Every byte string the kernels compare 8 bytes at a time has 16 readable bytes in front of it and 16 behind it
+// (S on the device, the packed reads, the LDS copy of a read), so that chunked loads never leave their buffer.
+constexpr int PADB = 16;
+
 struct PatD {           // read staged in LDS; out-of-range reads give '\0' like std::string::operator[](size())
     const uint8_t* p;
     int len;
     __device__ __forceinline__ uint32_t at(int i) const { return (i >= 0 && i < len) ? p[i] : 0u; }
+    __device__ __forceinline__ uint64_t load8(int i) const { return ld8(p + i); }   // caller keeps i in [-8, len+8]
 };
+
+// number of leading positions t < L with S[spos+t] == P[c+t]; needs spos+L <= N+16 and c+L <= |P|
+template <class PAT>
+__device__ __forceinline__ int match_fwd(const DIdx& X, const PAT& P, int64_t spos, int c, int L) {
+    int m = 0;
+    while (m < L) {
+        const uint64_t a0 = ld8(X.S + spos + m), a1 = ld8(X.S + spos + m + 8);
+        const uint64_t b0 = P.load8(c + m), b1 = P.load8(c + m + 8);
+        const uint64_t x0 = a0 ^ b0, x1 = a1 ^ b1;
+        if (x0) { m += __builtin_ctzll(x0) >> 3; break; }
+        if (x1) { m += 8 + (__builtin_ctzll(x1) >> 3); break; }
+        m += 16;
+    }
+    return m < L ? m : L;
+}
 
 // lcp-interval value of [start,end]  (sparseSA.cpp:751-754, 768-771)
 __device__ __forceinline__ int ival_lcp(const DIdx& X, int start, int end) {
-    const int ce = d_child(X, end);
-    if (start < ce && ce <= end) return d_lcp(X, ce);
-    return d_lcp(X, d_child(X, start));
+    const int ce = d_child(X, end), cs = d_child(X, start);
+    return d_lcp(X, (start < ce && ce <= end) ? ce : cs);
 }
 
 // top_down_child  sparseSA.cpp:671-697
+// (loads whose addresses do not depend on each other are issued together; the decisions are the reference's)
 __device__ bool td_child(const DIdx& X, uint32_t c, int& start, int& end, int depth) {
-    int left = start;
-    int right = d_child(X, end);
-    if (start >= right || right > end) right = d_child(X, start);
-    if (d_s(X, (int64_t)X.SA[start] + depth) == c) { end = right - 1; return true; }
-    left = right;
+    const int ce = d_child(X, end), cs = d_child(X, start);
+    const int64_t sa0 = (int64_t)X.SA[start];
+    int right = ce;
+    if (start >= right || right > end) right = cs;
+    if (d_s(X, sa0 + depth) == c) { end = right - 1; return true; }
+    int left = right;
     for (;;) {
+        // here left == right: the next sibling boundary, this boundary's lcp and this child's first suffix
         const int nxt = d_child(X, right);
-        if (!(nxt > right && d_lcp(X, right) == d_lcp(X, nxt))) break;
+        const int lcp_r = d_lcp(X, right);
+        const int64_t sal = (int64_t)X.SA[left];
+        const uint32_t ch = d_s(X, sal + depth);
+        if (!(nxt > right && lcp_r == d_lcp(X, nxt))) {
+            if (ch == c) { start = left; return true; }
+            return false;
+        }
         right = nxt;
-        if (d_s(X, (int64_t)X.SA[left] + depth) == c) { start = left; end = right - 1; return true; }
+        if (ch == c) { start = left; end = right - 1; return true; }
         left = right;
     }
-    if (d_s(X, (int64_t)X.SA[left] + depth) == c) { start = left; return true; }
-    return false;
 }
 
-// traverse_faster  sparseSA.cpp:733-791 with maxBranching = -1 (the only value the reference passes)
-__device__ void traverse_child(const DIdx& X, const PatD& P, int prefix, int& start, int& end, int& depth, int min_len) {
-    if (X.has_kmer && depth == 0 && min_len >= KMER) {
-        uint32_t index = 0;
-#pragma unroll
-        for (int i = 0; i < KMER; ++i) index = (index << 2) | bitadd(P.at(prefix + i));
-        if (index >= TABLE) return;
-        const uint2 lr = X.KMR[index];
-        if (lr.y == 0) return;
-        depth = KMER; start = (int)lr.x; end = (int)lr.y;
-    }
+// traverse_faster  sparseSA.cpp:733-791 with maxBranching = -1 (the only value the reference passes), after its 10-mer
+// table jump: continue the descent of [start,end] at `depth` until a mismatch, the end of the read or depth == min_len.
+// The function is resumable: stopping at some depth and calling it again with a larger min_len visits the same states
+// as one uninterrupted call (the reference itself resumes this way in findMEM/SMEM: mli -> xmi).
+// sa_hint: SA[start] when the caller already knows it (start == end), else -1.
+__device__ void traverse_from(const DIdx& X, const PatD& P, int prefix, int& start, int& end, int& depth, int min_len, int64_t sa_hint) {
     if (depth >= min_len) return;
     int c = prefix + depth;
-    bool found = c < P.len;
-    if (found) {
-        if (end > start && ival_lcp(X, start, end) == depth) found = td_child(X, P.at(c), start, end, depth);
-        else found = P.at(c) == d_s(X, (int64_t)X.SA[start] + depth);
+    if (c >= P.len) return;
+    if (start == end) {
+        // one suffix left: first character (:758) and the loop of :781-786 are one run of comparisons; the text ends at N.
+        // (Identical to the reference for reads without NUL bytes: S is NUL-padded behind N.)
+        const int64_t pos0 = (sa_hint >= 0 ? sa_hint : (int64_t)X.SA[start]) + depth;
+        const int L = min(P.len - c, min_len - depth);
+        const int Ls = (int)max((int64_t)0, min((int64_t)L, X.N - pos0));
+        depth += match_fwd(X, P, pos0, c, Ls);
+        return;
     }
+    bool found;
+    if (ival_lcp(X, start, end) == depth) found = td_child(X, P.at(c), start, end, depth);
+    else found = P.at(c) == d_s(X, (int64_t)X.SA[start] + depth);
     bool mism = false;
     while (found && !mism && c < P.len && depth < min_len) {
         ++c; ++depth;
         if (start != end) {
             const int childLCP = ival_lcp(X, start, end);
             const int minimum = childLCP < min_len ? childLCP : min_len;
-            const int64_t sp = (int64_t)X.SA[start];
-            while (!mism && c < P.len && depth < minimum) {
-                mism = d_s(X, sp + depth) != P.at(c);
-                ++c; depth += !mism;
+            // edge walk (the byte loop of :773-776), 16 bytes per round trip; S reads as '\0' from N+16 on
+            const int64_t pos0 = (int64_t)X.SA[start] + depth;
+            const int L = min(P.len - c, minimum - depth);
+            if (L > 0) {
+                const int Ls = (int)max((int64_t)0, min((int64_t)L, X.N + 16 - pos0));
+                const int m = match_fwd(X, P, pos0, c, Ls);
+                if (m < L) { mism = true; depth += m; c += m + 1; }
+                else { depth += L; c += L; }
             }
             found = c < P.len && !mism && depth < min_len && td_child(X, P.at(c), start, end, depth);
         } else {
-            const int64_t sp = (int64_t)X.SA[start];
-            while (!mism && c < P.len && depth < min_len) {
-                const int64_t pos = sp + depth;
-                mism = pos >= X.N || d_s(X, pos) != P.at(c);
-                ++c; depth += !mism;
+            // single suffix left (:781-786): compare on until a mismatch, the end of the text or of the read
+            const int64_t pos0 = (int64_t)X.SA[start] + depth;
+            const int L = min(P.len - c, min_len - depth);
+            if (L > 0) {
+                const int Ls = (int)max((int64_t)0, min((int64_t)L, X.N - pos0));
+                const int m = match_fwd(X, P, pos0, c, Ls);
+                if (m < L) { mism = true; depth += m; c += m + 1; }
+                else { depth += L; c += L; }
             }
         }
     }
 }
 
+__device__ __forceinline__ uint32_t kmer_code(const PatD& P, int prefix) {
+    uint32_t index = 0;
+#pragma unroll
+    for (int i = 0; i < KMER; ++i) index = (index << 2) | bitadd(P.at(prefix + i));
+    return index;
+}
+
+__device__ void traverse_child(const DIdx& X, const PatD& P, int prefix, int& start, int& end, int& depth, int min_len) {
+    int64_t sa_hint = -1;
+    if (X.has_kmer && depth == 0 && min_len >= KMER) {          // :734-746
+        const uint32_t index = kmer_code(P, prefix);
+        if (index >= TABLE) return;
+        if (!((X.KBIT[index >> 5] >> (index & 31)) & 1u)) return;   // right == 0: no sampled suffix starts with this 10-mer
+        const uint4 e = X.KMR2[index];
+        depth = KMER; start = (int)e.x; end = (int)e.y;
+        if (start == end) sa_hint = (int64_t)e.z;
+    }
+    traverse_from(X, P, prefix, start, end, depth, min_len, sa_hint);
+}
+
 // find_LmaximalStrict  sparseSA.cpp:858-871.  Returns true (and the match) when one is emitted.
+// The reference steps left one character at a time, at most `border` times, and emits only when it stops on a left
+// mismatch, the text start or the read start.  Same decision here from the length m of the common left extension
+// (capped at min(border, prefix, i)), compared 16 bytes per round trip: emitted iff m < border.
 template <class PAT>
 __device__ __forceinline__ bool lmax_strict(const DIdx& X, const PAT& P, int prefix, int64_t i, int len, int min_len, int border,
                                             int64_t& mref, int& mq, int& mlen) {
-    for (int k = 0; k < border; ++k) {
-        if (prefix == 0 || i == 0 || P.at(prefix - 1) != d_s(X, i - 1)) {
-            if (len >= min_len) { mref = i; mq = prefix; mlen = len; return true; }
-            return false;
-        }
-        --prefix; --i; ++len;
+    if (border <= 0) return false;
+    const int lim = (int)min((int64_t)min(border, prefix), i);
+    int m = 0;
+    while (m < lim) {
+        // S[i-m-8 .. i-m-1] against P[prefix-m-8 .. prefix-m-1]: the byte next to the match is the most significant one
+        const uint64_t a0 = ld8(X.S + i - m - 8), a1 = ld8(X.S + i - m - 16);
+        const uint64_t b0 = P.load8(prefix - m - 8), b1 = P.load8(prefix - m - 16);
+        const uint64_t x0 = a0 ^ b0, x1 = a1 ^ b1;
+        if (x0) { m += __builtin_clzll(x0) >> 3; break; }
+        if (x1) { m += 8 + (__builtin_clzll(x1) >> 3); break; }
+        m += 16;
     }
-    return false;
+    if (m > lim) m = lim;
+    if (m >= border) return false;
+    if (len + m < min_len) return false;
+    mref = i - m; mq = prefix - m; mlen = len + m;
+    return true;
 }
 
 // top_down_faster  sparseSA.cpp:614-666 (binary search on the i-th character, no child table)
@@ -359,8 +437,145 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh, int& total) {
     return base + inc - v;
 }
 
+// Work-list slots for the lanes of a converged wave that `want` one: a single atomic per wave.  (One atomic per lane on one
+// address was the bottleneck of the first version of these kernels: ~10^6 same-address device atomics per launch, each
+// wave's life dominated by the wait for its turn.)
+__device__ __forceinline__ int wave_alloc_slot(int* counter, bool want) {
+    const uint64_t m = __ballot(want);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, 0, 64);
+    return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
 // ---------------------------------------------------------------- kernel A: traverse + count
-__global__ __launch_bounds__(SEED_BLOCK) void smam_count_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
+// Counters (rocprofv3, profiles/) show the one-read-per-workgroup form bound by the vector L1's miss path: ~250 L1->L2
+// requests per read strand, the L1 stalled on pending L2 data for 3/4 of the kernel, waves waiting 80 % of their life.
+// Nearly half of those requests are probes of the 10-mer table that find it empty, and most of the rest are the first
+// characters of random 10-mer hits.  This form removes both:
+//   * persistent workgroups, one per CU (1024 threads), keep the 128 KiB 10-mer presence bitmap in LDS;
+//   * the companion table KMR2 carries, for single-suffix entries, SA[left] and the 4 text bytes behind the 10-mer, so a
+//     random hit is resolved from the table entry alone;
+//   * a wave owns a read strand (its bytes in the wave's LDS slice) and takes the next one from a global counter; offsets
+//     come from a wave-level scan, so the main loop has no workgroup barrier.
+constexpr int PBLOCK = 1024;
+constexpr int PWAVES = PBLOCK / 64;
+constexpr int KBIT_BYTES = (int)(TABLE / 8);
+
+__device__ __forceinline__ int wave_excl_scan(int v, int& total) {
+    const int lane = threadIdx.x & 63;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    total = __shfl(inc, 63, 64);
+    return inc - v;
+}
+
+__global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
+                                                           int64_t* __restrict__ read_total, WorkRec* __restrict__ work,
+                                                           int* __restrict__ seg_count, int seg_cap, int nq, int lds_stride) {
+    extern __shared__ uint8_t smem[];
+    __shared__ int sh_wcount;                                   // records in this workgroup's segment of the work list
+    uint32_t* bits = (uint32_t*)smem;
+    for (int i = threadIdx.x; i < (int)(TABLE / 32); i += PBLOCK) bits[i] = X.KBIT[i];
+    if (threadIdx.x == 0) sh_wcount = 0;
+    __syncthreads();
+    work += (size_t)blockIdx.x * seg_cap;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint8_t* mybuf = smem + KBIT_BYTES + (size_t)wid * lds_stride;
+    const int K = X.K;
+    for (int r = blockIdx.x * PWAVES + wid; r < nq; r += gridDim.x * PWAVES) {      // wave-uniform
+        const SeedQ Q = qs[r];
+        PatD P;
+        P.len = Q.plen;
+        if (Q.plen + 2 * PADB <= lds_stride) {
+            for (int i = lane; i < Q.plen; i += 64) mybuf[PADB + i] = reads[Q.poff + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            P.p = mybuf + PADB;
+        } else {
+            P.p = reads + Q.poff;
+        }
+        const int step = Q.sparse_q * K;
+        const int min_lenK = Q.min_len - (step - 1);
+        const int minMin_len = Q.sparse_q > 1 ? Q.min_len - K : Q.min_len;
+        PrefixMap pm;
+        pm.step = step;
+        pm.Lmax = Q.plen - min_lenK;
+        pm.nh = pm.Lmax >= 0 ? pm.Lmax / step + 1 : 0;
+        {
+            const int kk = K < pm.Lmax + 1 ? K : pm.Lmax + 1;
+            const int rr = pm.Lmax >= 0 ? pm.Lmax % step : 0;
+            pm.kh = kk < rr + 1 ? kk : rr + 1;
+        }
+        const int maxCount = Q.sparse_q * Q.max_count;
+        const bool use_kmer = Q.plen >= KMER;                   // traverse_faster is called with min_len = |P| (:1073)
+        int running = 0;
+        for (int base = 0; base < Q.npref; base += 64) {
+            const int t = base + lane;
+            int cnt = 0, start = 0, end = X.n - 1, depth = 0, prefix = 0;
+            if (t < Q.npref) {
+                prefix = pm.prefix_of(t);
+                int64_t sa = -1;
+                bool alive = true, done = false;
+                if (use_kmer) {
+                    const uint32_t index = kmer_code(P, prefix);
+                    alive = index < TABLE && ((bits[index >> 5] >> (index & 31)) & 1u);
+                    if (alive) {
+                        const uint4 e = X.KMR2[index];
+                        depth = KMER; start = (int)e.x; end = (int)e.y;
+                        if (start == end) {
+                            // single suffix: the run of comparisons of :758,:781-786, its first 4 characters from the table entry
+                            sa = (int64_t)e.z;
+                            const int c = prefix + KMER;
+                            const int64_t pos0 = sa + KMER;
+                            const int Ls = (int)max((int64_t)0, min((int64_t)(Q.plen - c), X.N - pos0));
+                            if (Ls > 0) {
+                                const uint32_t x = e.w ^ (uint32_t)P.load8(c);
+                                const int m4 = x ? (__builtin_ctz(x) >> 3) : 4;
+                                if (m4 < 4 || Ls <= 4) depth += min(m4, Ls);
+                                else depth += 4 + match_fwd(X, P, pos0 + 4, c + 4, Ls - 4);
+                            }
+                            done = true;
+                        }
+                    }
+                }
+                if (alive && !done) traverse_from(X, P, prefix, start, end, depth, Q.plen, -1);
+                if (alive && depth > 1 && depth >= min_lenK && (end - start + 1) <= maxCount) {
+                    int64_t mr; int mq, ml;
+                    if (start == end && sa >= 0) cnt = lmax_strict(X, P, prefix, sa, depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
+                    else
+                        for (int i = start; i <= end; ++i)
+                            cnt += lmax_strict(X, P, prefix, (int64_t)X.SA[i], depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
+                }
+            }
+            int total;
+            const int excl = wave_excl_scan(cnt, total);
+            const int slot = wave_alloc_slot(&sh_wcount, cnt > 0);
+            if (cnt > 0) {
+                if (slot < seg_cap) {
+                    WorkRec w;
+                    w.read = r; w.woff = running + excl; w.start = start; w.end = end; w.depth = depth; w.prefix = prefix;
+                    work[slot] = w;
+                }
+            }
+            running += total;
+        }
+        if (lane == 0) read_total[r] = running;
+        __builtin_amdgcn_wave_barrier();                        // the LDS slice is rewritten for the next read
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) seg_count[blockIdx.x] = sh_wcount;
+}
+
+// ---------------------------------------------------------------- kernel A, plain form: one read per workgroup, every lane walks
+// its query to the end (used for indexes without a child table)
+__global__ __launch_bounds__(SEED_BLOCK) void smam_count_simple_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
                                                                int64_t* __restrict__ read_total, WorkRec* __restrict__ work,
                                                                int* __restrict__ work_count, int work_cap, int lds_p) {
     extern __shared__ uint8_t smem[];
@@ -371,9 +586,9 @@ __global__ __launch_bounds__(SEED_BLOCK) void smam_count_kernel(DIdx X, const Se
     PatD P;
     P.len = Q.plen;
     if (lds_p) {
-        for (int i = tid; i < Q.plen; i += SEED_BLOCK) smem[i] = reads[Q.poff + i];
+        for (int i = tid; i < Q.plen; i += SEED_BLOCK) smem[PADB + i] = reads[Q.poff + i];
         __syncthreads();
-        P.p = smem;
+        P.p = smem + PADB;
     } else {
         P.p = reads + Q.poff;
     }
@@ -409,8 +624,8 @@ __global__ __launch_bounds__(SEED_BLOCK) void smam_count_kernel(DIdx X, const Se
         }
         int total;
         const int excl = block_excl_scan(cnt, sh_scan, total);
+        const int slot = wave_alloc_slot(work_count, cnt > 0);
         if (cnt > 0) {
-            const int slot = atomicAdd(work_count, 1);
             if (slot < work_cap) {
                 WorkRec w;
                 w.read = r; w.woff = running + excl; w.start = start; w.end = end; w.depth = depth; w.prefix = prefix;
@@ -426,18 +641,20 @@ struct PatG {   // read bytes straight from global memory (kernel B touches only
     const uint8_t* p;
     int len;
     __device__ __forceinline__ uint32_t at(int i) const { return (i >= 0 && i < len) ? p[i] : 0u; }
+    __device__ __forceinline__ uint64_t load8(int i) const { return ld8(p + i); }
 };
 
 // ---------------------------------------------------------------- kernel B: emit
 __global__ void smam_emit_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
                                  const int64_t* __restrict__ read_base, int nq, const WorkRec* __restrict__ work,
-                                 const int* __restrict__ work_count, int work_cap, alfa_match* __restrict__ out, int64_t out_cap) {
+                                 const int* __restrict__ seg_count, int seg_cap, alfa_match* __restrict__ out, int64_t out_cap) {
+    // the work list is segmented (one segment per producing workgroup of the persistent kernel, else a single one):
+    // blockIdx.y = segment.  An overflowing segment or match array is detected by the host at fetch time, which
+    // re-launches with larger buffers; records beyond a segment's capacity were never written.
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nwork = *work_count;
-    // an overflowing work list or match array is detected by the host at fetch time, which re-launches with
-    // larger buffers; nothing is written here in that case
-    if (nwork > work_cap || read_base[nq] > out_cap || g >= nwork) return;
-    const WorkRec w = work[g];
+    const int nwork = min(seg_count[blockIdx.y], seg_cap);
+    if (read_base[nq] > out_cap || g >= nwork) return;
+    const WorkRec w = work[(size_t)blockIdx.y * seg_cap + g];
     const SeedQ Q = qs[w.read];
     PatG P; P.p = reads + Q.poff; P.len = Q.plen;
     const int K = X.K;
@@ -465,9 +682,9 @@ __global__ __launch_bounds__(SEED_BLOCK) void mem_count_kernel(DIdx X, const See
     PatD P;
     P.len = Q.plen;
     if (lds_p) {
-        for (int i = tid; i < Q.plen; i += SEED_BLOCK) smem[i] = reads[Q.poff + i];
+        for (int i = tid; i < Q.plen; i += SEED_BLOCK) smem[PADB + i] = reads[Q.poff + i];
         __syncthreads();
-        P.p = smem;
+        P.p = smem + PADB;
     } else {
         P.p = reads + Q.poff;
     }
@@ -499,8 +716,8 @@ __global__ __launch_bounds__(SEED_BLOCK) void mem_count_kernel(DIdx X, const See
         }
         int total;
         const int excl = block_excl_scan(cnt, sh_scan, total);
+        const int slot = wave_alloc_slot(work_count, cnt > 0);
         if (cnt > 0) {
-            const int slot = atomicAdd(work_count, 1);
             if (slot < work_cap) {
                 WorkRec2 w;
                 w.read = r; w.woff = running + excl; w.prefix = prefix;
@@ -531,10 +748,10 @@ __global__ __launch_bounds__(SEED_BLOCK) void smem_count_kernel(DIdx X, const Se
     const int tid = threadIdx.x;
     PatD P;
     P.len = Q.plen;
-    const int pbytes = (Q.plen + 15) & ~15;
+    const int pbytes = ((Q.plen + 15) & ~15) + 2 * PADB;
     if (lds_p) {
-        for (int i = tid; i < Q.plen; i += SEED_BLOCK) smem[i] = reads[Q.poff + i];
-        P.p = smem;
+        for (int i = tid; i < Q.plen; i += SEED_BLOCK) smem[PADB + i] = reads[Q.poff + i];
+        P.p = smem + PADB;
     } else {
         P.p = reads + Q.poff;
     }
@@ -651,8 +868,8 @@ __global__ __launch_bounds__(SEED_BLOCK) void smem_count_kernel(DIdx X, const Se
         }
         int total;
         const int excl = block_excl_scan(cnt, sh_scan, total);
+        const int slot = wave_alloc_slot(work_count, cnt > 0);
         if (cnt > 0) {
-            const int slot = atomicAdd(work_count, 1);
             if (slot < work_cap) {
                 WorkRec2 w;
                 w.read = r; w.woff = running + excl; w.prefix = p;
@@ -669,12 +886,12 @@ __global__ __launch_bounds__(SEED_BLOCK) void smem_count_kernel(DIdx X, const Se
 // ---------------------------------------------------------------- MEM / SMEM: emit
 template <int TYPE>
 __global__ void emit2_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads, const int64_t* __restrict__ read_base,
-                             int nq, const WorkRec2* __restrict__ work, const int* __restrict__ work_count, int work_cap,
+                             int nq, const WorkRec2* __restrict__ work, const int* __restrict__ seg_count, int seg_cap,
                              alfa_match* __restrict__ out, int64_t out_cap) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nwork = *work_count;
-    if (nwork > work_cap || read_base[nq] > out_cap || g >= nwork) return;
-    const WorkRec2 w = work[g];
+    const int nwork = min(seg_count[blockIdx.y], seg_cap);
+    if (read_base[nq] > out_cap || g >= nwork) return;
+    const WorkRec2 w = work[(size_t)blockIdx.y * seg_cap + g];
     const SeedQ Q = qs[w.read];
     PatG P; P.p = reads + Q.poff; P.len = Q.plen;
     const int K = X.K;
@@ -705,6 +922,15 @@ int64_t count_prefixes_smem(int64_t K, int plen, int min_len, int sparse_q) {
     return std::max<int64_t>(0, (int64_t)plen - min_lenK + 1);
 }
 
+// S with PADB zero bytes in front and 32 behind (the kernels compare 16 bytes per step)
+int upload_padded(alfa::DevBuf& b, const void* src, size_t bytes) {
+    int rc = b.reserve(bytes + PADB + 32 + 16);
+    if (rc) return rc;
+    ALFA_HIP(hipMemset(b.p, 0, bytes + PADB + 32 + 16));
+    if (bytes) ALFA_HIP(hipMemcpy((char*)b.p + PADB, src, bytes, hipMemcpyHostToDevice));
+    return ALFA_OK;
+}
+
 int upload(alfa::DevBuf& b, const void* src, size_t bytes, size_t pad = 0) {
     int rc = b.reserve(bytes + pad + 16);
     if (rc) return rc;
@@ -728,13 +954,29 @@ int alfa_index_upload(const alfa_index_view* v, int device, alfa_index** out) {
     ix->N = v->N; ix->n = v->n; ix->K = v->K; ix->logN = v->logN; ix->NKm1 = v->NKm1; ix->nM = v->nM;
     ix->has_child = v->has_child && v->CHILD; ix->has_suflink = v->has_suflink; ix->has_kmer = v->has_kmer && v->KMR;
     int rc = ALFA_OK;
-    if ((rc = upload(ix->S, v->S, (size_t)v->N, 32)) || (rc = upload(ix->SA, v->SA, 4 * (size_t)v->n)) ||
+    if ((rc = upload_padded(ix->S, v->S, (size_t)v->N)) || (rc = upload(ix->SA, v->SA, 4 * (size_t)v->n)) ||
         (rc = upload(ix->LCP, v->LCP, (size_t)v->n)) || (rc = upload(ix->Midx, v->LCP_M_idx, 8 * (size_t)v->nM)) ||
         (rc = upload(ix->Mval, v->LCP_M_val, 4 * (size_t)v->nM)) ||
         (ix->has_child && (rc = upload(ix->CHILD, v->CHILD, 4 * (size_t)v->n))) ||
         (ix->has_kmer && (rc = upload(ix->KMR, v->KMR, 8 * (size_t)TABLE)))) {
         alfa_index_free(ix);
         return rc;
+    }
+    if (ix->has_kmer) {
+        // device-side companions of the 10-mer table (layout is ours; content is a function of KMR and SA only)
+        std::vector<uint32_t> k2(4 * (size_t)TABLE), kb(TABLE / 32, 0u);
+        for (size_t i = 0; i < TABLE; ++i) {
+            const uint32_t l = v->KMR[2 * i], r = v->KMR[2 * i + 1];
+            const uint32_t sa = (l < (uint64_t)v->n) ? v->SA[l] : 0u;
+            uint32_t nxt = 0;        // S[sa+10 .. sa+13] (the host S carries 16 NUL bytes behind N)
+            if ((int64_t)sa + KMER + 4 <= v->N + 16) memcpy(&nxt, v->S + sa + KMER, 4);
+            k2[4 * i] = l; k2[4 * i + 1] = r; k2[4 * i + 2] = sa; k2[4 * i + 3] = nxt;
+            if (r > 0) kb[i >> 5] |= 1u << (i & 31);
+        }
+        if ((rc = upload(ix->KMR2, k2.data(), 16 * (size_t)TABLE)) || (rc = upload(ix->KBIT, kb.data(), TABLE / 8))) {
+            alfa_index_free(ix);
+            return rc;
+        }
     }
     *out = ix;
     return ALFA_OK;
@@ -743,7 +985,7 @@ int alfa_index_upload(const alfa_index_view* v, int device, alfa_index** out) {
 void alfa_index_free(alfa_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    ix->S.release(); ix->SA.release(); ix->LCP.release(); ix->Midx.release(); ix->Mval.release(); ix->CHILD.release(); ix->KMR.release();
+    ix->S.release(); ix->SA.release(); ix->LCP.release(); ix->Midx.release(); ix->Mval.release(); ix->CHILD.release(); ix->KMR.release(); ix->KMR2.release(); ix->KBIT.release();
     delete ix;
 }
 
@@ -756,9 +998,11 @@ struct alfa_seed_plan {
     int nq = 0, max_plen = 0;
     int64_t total_pref = 0;
     size_t read_bytes = 0;
-    int work_cap = 0;
+    int nseg = 1, seg_cap = 0;   // work list: nseg segments of seg_cap records (persistent SMAM kernel: one per workgroup)
+    bool persistent = false;
+    int stride = 0;              // persistent kernel: LDS bytes per wave for its read
     int64_t out_cap = 0;
-    alfa::DevBuf d_reads, d_q, d_tot, d_base, d_work, d_out, d_tmp, d_scr;
+    alfa::DevBuf d_reads, d_q, d_tot, d_base, d_work, d_cnt, d_out, d_tmp, d_scr;
     size_t tmp_bytes = 0;
     int mem_type = ALFA_SEED_SMAM;
     size_t work_rec = sizeof(WorkRec);
@@ -772,9 +1016,9 @@ namespace {
 
 DIdx make_didx(const alfa_index* ix) {
     DIdx X;
-    X.S = ix->S.as<uint8_t>(); X.SA = ix->SA.as<uint32_t>(); X.LCP = ix->LCP.as<uint8_t>();
+    X.S = ix->S.as<uint8_t>() + PADB; X.SA = ix->SA.as<uint32_t>(); X.LCP = ix->LCP.as<uint8_t>();
     X.Midx = ix->Midx.as<int64_t>(); X.Mval = ix->Mval.as<int32_t>(); X.CHILD = ix->CHILD.as<int32_t>();
-    X.KMR = ix->KMR.as<uint2>();
+    X.KMR = ix->KMR.as<uint2>(); X.KMR2 = ix->KMR2.as<uint4>(); X.KBIT = ix->KBIT.as<uint32_t>();
     X.N = ix->N; X.n = (int32_t)ix->n; X.nM = (int32_t)ix->nM; X.K = (int32_t)ix->K; X.has_kmer = ix->has_kmer; X.has_child = ix->has_child;
     return X;
 }
@@ -799,13 +1043,15 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
     pl->read_bytes = bytes; pl->max_plen = max_plen;
     if (nq == 0) return ALFA_OK;
     int rc;
+    bytes += PADB;    // front pad; the reserve below adds the pad behind the last read
     if ((rc = cx->h_in.reserve(bytes + 64)) || (rc = cx->h_tasks.reserve(sizeof(SeedQ) * (size_t)nq)) ||
         (rc = pl->d_reads.reserve(bytes + 64)) || (rc = pl->d_q.reserve(sizeof(SeedQ) * (size_t)nq)) ||
         (rc = pl->d_tot.reserve(8 * ((size_t)nq + 1) + 64)) || (rc = pl->d_base.reserve(8 * ((size_t)nq + 1) + 64)))
         return rc;
     uint8_t* hp = cx->h_in.as<uint8_t>();
     SeedQ* hq = cx->h_tasks.as<SeedQ>();
-    size_t po = 0;
+    size_t po = PADB;
+    memset(hp, 0, PADB);
     int64_t total_pref = 0, scr_ints = 0;
     int max_w = 0;
     for (int i = 0; i < nq; ++i) {
@@ -828,15 +1074,32 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
     pl->total_pref = total_pref;
     pl->max_w = max_w;
     if (mem_type == ALFA_SEED_SMEM) {
-        const size_t pbytes = max_plen <= 48 * 1024 ? (((size_t)max_plen + 15) & ~(size_t)15) : 0;
+        const size_t pbytes = max_plen <= 48 * 1024 ? (((size_t)max_plen + 15) & ~(size_t)15) + 2 * PADB : 0;
         pl->lds_tab = pbytes + (size_t)SMEM_TABLES * 4 * (size_t)max_w + 64 <= 60 * 1024;
         if (!pl->lds_tab && (rc = pl->d_scr.reserve(4 * (size_t)scr_ints + 64))) return rc;
     }
-    pl->work_cap = (int)std::min<int64_t>(std::max<int64_t>(4096, 4 * (int64_t)nq), std::max<int64_t>(total_pref, 1));
+    static const bool force_simple = getenv("ALFA_SEED_SIMPLE") != nullptr;   // A/B switch for profiling
+    pl->persistent = mem_type == ALFA_SEED_SMAM && ix->has_child && ix->has_kmer && !force_simple;
+    pl->nseg = 1;
+    if (pl->persistent) {
+        static int n_cu[64] = {0};
+        int& ncu = n_cu[ix->device & 63];
+        if (!ncu) {
+            hipDeviceProp_t prop;
+            ALFA_HIP(hipGetDeviceProperties(&prop, ix->device));
+            ALFA_HIP(hipFuncSetAttribute((const void*)smam_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+            ncu = std::max(1, prop.multiProcessorCount);
+        }
+        pl->nseg = std::max(1, std::min(ncu, (nq + PWAVES - 1) / PWAVES));
+        const int room = (160 * 1024 - KBIT_BYTES - 1024) / PWAVES;                       // LDS bytes a wave can have for its read
+        pl->stride = std::min(room & ~15, (max_plen + 2 * PADB + 15) & ~15);              // longer reads are read from global memory
+    }
+    const int64_t total_cap = std::min<int64_t>(std::max<int64_t>(4096, 4 * (int64_t)nq), std::max<int64_t>(total_pref, 1));
+    pl->seg_cap = pl->nseg == 1 ? (int)total_cap : (int)std::max<int64_t>(256, 2 * total_cap / pl->nseg);
     pl->out_cap = std::max<int64_t>(4096, 16 * (int64_t)nq);
     pl->tmp_bytes = 0;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, pl->tmp_bytes, pl->d_tot.as<int64_t>(), pl->d_base.as<int64_t>(), nq + 1, cx->stream));
-    if ((rc = pl->d_work.reserve(pl->work_rec * (size_t)pl->work_cap + 64)) ||
+    if ((rc = pl->d_work.reserve(pl->work_rec * (size_t)pl->nseg * (size_t)pl->seg_cap + 64)) || (rc = pl->d_cnt.reserve(4 * (size_t)pl->nseg + 64)) ||
         (rc = pl->d_out.reserve(sizeof(alfa_match) * (size_t)pl->out_cap)) || (rc = pl->d_tmp.reserve(pl->tmp_bytes + 64)))
         return rc;
     ALFA_HIP(hipMemcpyAsync(pl->d_reads.p, hp, bytes, hipMemcpyHostToDevice, cx->stream));
@@ -852,40 +1115,45 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
     const DIdx X = make_didx(pl->ix);
     const int nq = pl->nq;
     const int lds_p = pl->max_plen <= 48 * 1024;
-    const size_t lds_bytes = lds_p ? (size_t)pl->max_plen + 16 : 0;
-    int* d_wc = (int*)((char*)pl->d_work.p + pl->work_rec * (size_t)pl->work_cap);
+    const size_t lds_bytes = lds_p ? (size_t)pl->max_plen + 2 * PADB + 16 : 0;
+    int* d_cnt = pl->d_cnt.as<int>();
     int64_t* d_tot = pl->d_tot.as<int64_t>();
     int64_t* d_base = pl->d_base.as<int64_t>();
     const SeedQ* d_q = pl->d_q.as<SeedQ>();
     const uint8_t* d_reads = pl->d_reads.as<uint8_t>();
-    ALFA_HIP(hipMemsetAsync(d_wc, 0, 4, st));
+    ALFA_HIP(hipMemsetAsync(d_cnt, 0, 4 * (size_t)pl->nseg, st));
     ALFA_HIP(hipMemsetAsync(d_tot + nq, 0, 8, st));
     ALFA_HIP(hipEventRecord(pl->ev0, st));
-    if (pl->mem_type == ALFA_SEED_SMAM) {
-        hipLaunchKernelGGL(smam_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec>(), d_wc,
-                           pl->work_cap, lds_p);
+    if (pl->persistent) {
+        // one workgroup per CU, the 10-mer bitmap + one read slice per wave in LDS
+        const size_t lds = (size_t)KBIT_BYTES + (size_t)PWAVES * pl->stride;
+        hipLaunchKernelGGL(smam_count_kernel, dim3(pl->nseg), dim3(PBLOCK), lds, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec>(), d_cnt,
+                           pl->seg_cap, nq, pl->stride);
+    } else if (pl->mem_type == ALFA_SEED_SMAM) {
+        hipLaunchKernelGGL(smam_count_simple_kernel, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec>(),
+                           d_cnt, pl->seg_cap, lds_p);
     } else if (pl->mem_type == ALFA_SEED_MEM) {
-        hipLaunchKernelGGL(mem_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec2>(), d_wc,
-                           pl->work_cap, lds_p);
+        hipLaunchKernelGGL(mem_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec2>(), d_cnt,
+                           pl->seg_cap, lds_p);
     } else {
-        const size_t pbytes = lds_p ? (((size_t)pl->max_plen + 15) & ~(size_t)15) : 0;
+        const size_t pbytes = lds_p ? (((size_t)pl->max_plen + 15) & ~(size_t)15) + 2 * PADB : 0;
         const size_t lds2 = pbytes + (pl->lds_tab ? (size_t)SMEM_TABLES * 4 * (size_t)pl->max_w : 0) + 16;
-        hipLaunchKernelGGL(smem_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds2, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec2>(), d_wc,
-                           pl->work_cap, lds_p, pl->lds_tab ? 1 : 0, pl->d_scr.as<int>());
+        hipLaunchKernelGGL(smem_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds2, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec2>(), d_cnt,
+                           pl->seg_cap, lds_p, pl->lds_tab ? 1 : 0, pl->d_scr.as<int>());
     }
     ALFA_HIP(hipGetLastError());
     ALFA_HIP(hipEventRecord(pl->ev1, st));
     size_t tb = pl->tmp_bytes;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_tmp.p, tb, d_tot, d_base, nq + 1, st));
-    const dim3 eg((pl->work_cap + 127) / 128), eb(128);
+    const dim3 eg((pl->seg_cap + 127) / 128, pl->nseg), eb(128);
     if (pl->mem_type == ALFA_SEED_SMAM)
-        hipLaunchKernelGGL(smam_emit_kernel, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec>(), d_wc, pl->work_cap,
+        hipLaunchKernelGGL(smam_emit_kernel, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec>(), d_cnt, pl->seg_cap,
                            pl->d_out.as<alfa_match>(), pl->out_cap);
     else if (pl->mem_type == ALFA_SEED_MEM)
-        hipLaunchKernelGGL(emit2_kernel<ALFA_SEED_MEM>, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec2>(), d_wc, pl->work_cap,
+        hipLaunchKernelGGL(emit2_kernel<ALFA_SEED_MEM>, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec2>(), d_cnt, pl->seg_cap,
                            pl->d_out.as<alfa_match>(), pl->out_cap);
     else
-        hipLaunchKernelGGL(emit2_kernel<ALFA_SEED_SMEM>, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec2>(), d_wc, pl->work_cap,
+        hipLaunchKernelGGL(emit2_kernel<ALFA_SEED_SMEM>, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec2>(), d_cnt, pl->seg_cap,
                            pl->d_out.as<alfa_match>(), pl->out_cap);
     ALFA_HIP(hipGetLastError());
     return ALFA_OK;
@@ -899,18 +1167,18 @@ int plan_fetch(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_match** matches, int64_t*
     hipStream_t st = cx->stream;
     int rc;
     for (int attempt = 0;; ++attempt) {
-        int nwork = 0;
-        int* d_wc = (int*)((char*)pl->d_work.p + pl->work_rec * (size_t)pl->work_cap);
-        ALFA_HIP(hipMemcpyAsync(&nwork, d_wc, 4, hipMemcpyDeviceToHost, st));
+        std::vector<int> segc((size_t)pl->nseg);
+        ALFA_HIP(hipMemcpyAsync(segc.data(), pl->d_cnt.p, 4 * (size_t)pl->nseg, hipMemcpyDeviceToHost, st));
         ALFA_HIP(hipMemcpyAsync(offsets, pl->d_base.p, 8 * ((size_t)nq + 1), hipMemcpyDeviceToHost, st));
         ALFA_HIP(hipStreamSynchronize(st));
         const int64_t total = offsets[nq];
-        if (nwork <= pl->work_cap && total <= pl->out_cap) break;
+        const int nwork = *std::max_element(segc.begin(), segc.end());
+        if (nwork <= pl->seg_cap && total <= pl->out_cap) break;
         if (attempt >= 2) return alfa::fail(ALFA_EHIP, "seed work list kept overflowing");
-        // grow to the exact need reported by the device and run again
-        if (nwork > pl->work_cap) {
-            pl->work_cap = nwork;
-            if ((rc = pl->d_work.reserve(pl->work_rec * (size_t)pl->work_cap + 64))) return rc;
+        // grow to the need reported by the device and run again
+        if (nwork > pl->seg_cap) {
+            pl->seg_cap = pl->nseg == 1 ? nwork : nwork + nwork / 8 + 64;
+            if ((rc = pl->d_work.reserve(pl->work_rec * (size_t)pl->nseg * (size_t)pl->seg_cap + 64))) return rc;
         }
         if (total > pl->out_cap) {
             pl->out_cap = total;
@@ -932,7 +1200,7 @@ int plan_fetch(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_match** matches, int64_t*
 
 void plan_release(alfa_seed_plan* pl) {
     pl->d_reads.release(); pl->d_q.release(); pl->d_tot.release(); pl->d_base.release(); pl->d_work.release(); pl->d_out.release();
-    pl->d_tmp.release(); pl->d_scr.release();
+    pl->d_tmp.release(); pl->d_scr.release(); pl->d_cnt.release();
     if (pl->ev0) { (void)hipEventDestroy(pl->ev0); (void)hipEventDestroy(pl->ev1); pl->ev0 = pl->ev1 = nullptr; }
 }
 
