@@ -56,6 +56,26 @@ class ExtendResult(C.Structure):
 EXTEND_DTYPE = np.dtype([("score", "<i4"), ("qle", "<i4"), ("tle", "<i4"), ("gtle", "<i4"), ("gscore", "<i4"), ("max_off", "<i4")])
 
 
+class DpbandTask(C.Structure):      # alfa_dpband_task
+    _fields_ = [("ref", C.c_char_p), ("ref_len", C.c_int64), ("query", C.c_char_p), ("query_len", C.c_int64),
+                ("refB", C.c_int64), ("refE", C.c_int64), ("queryB", C.c_int32), ("queryE", C.c_int32),
+                ("freeRefB", C.c_uint8), ("freeRefE", C.c_uint8), ("freeQueryB", C.c_uint8), ("freeQueryE", C.c_uint8),
+                ("local", C.c_uint8), ("out_type", C.c_int32), ("band1", C.c_int32), ("band2", C.c_int32)]
+
+
+class DpbandScores(C.Structure):    # alfa_dpband_scores
+    _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("openGap", C.c_int32), ("extendGap", C.c_int32),
+                ("affine", C.c_int32)]
+
+
+class DpbandResult(C.Structure):    # alfa_dpband_result
+    _fields_ = [("ret", C.c_int32), ("dpScore", C.c_int32), ("editDist", C.c_int32), ("refB", C.c_int64), ("refE", C.c_int64),
+                ("queryB", C.c_int32), ("queryE", C.c_int32), ("n_cigar", C.c_int32), ("cig_off", C.c_int64)]
+
+
+DPBAND_STATIC, DPBAND_FULL, DPBAND_SCORE, DPBAND_BASIC = 0, 1, 2, 3
+
+
 class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
                 ("work_units", C.c_int64), ("launches", C.c_int32)]
@@ -293,6 +313,47 @@ def ksw_global_batch(params, tasks):
         check(rc)
         return rc
     return _global_call(fn, params, tasks, lib().alfa_free)
+
+
+def make_dpband_tasks(specs):
+    """specs: dicts with ref, query (bytes) and optional refB, refE, queryB, queryE, flags (5 bools: freeRefB, freeRefE, freeQueryB,
+    freeQueryE, local), out_type, band1, band2"""
+    t = (DpbandTask * len(specs))()
+    for i, sp in enumerate(specs):
+        r, q = sp["ref"], sp["query"]
+        t[i].ref, t[i].ref_len, t[i].query, t[i].query_len = r, len(r), q, len(q)
+        t[i].refB, t[i].refE = sp.get("refB", 0), sp.get("refE", len(r) - 1)
+        t[i].queryB, t[i].queryE = sp.get("queryB", 0), sp.get("queryE", len(q) - 1)
+        f = sp.get("flags", (0, 0, 0, 0, 0))
+        t[i].freeRefB, t[i].freeRefE, t[i].freeQueryB, t[i].freeQueryE, t[i].local = [int(bool(x)) for x in f]
+        t[i].out_type, t[i].band1, t[i].band2 = sp.get("out_type", 4), sp.get("band1", 10), sp.get("band2", 10)
+    t._keep = specs
+    return t
+
+
+def dpband_call(fn, variant, scores, tasks, free_fn):
+    """-> list of (ret, dpScore, editDist, refB, refE, queryB, queryE, cigar) with cigar like '12=1X3D'"""
+    n = len(tasks)
+    res = (DpbandResult * max(n, 1))()
+    cc, cl = C.c_void_p(), C.c_void_p()
+    check(fn(int(variant), C.byref(scores), tasks, n, res, C.byref(cc), C.byref(cl)))
+    out = []
+    for i in range(n):
+        r = res[i]
+        cig = ""
+        if r.n_cigar > 0:
+            ch = C.string_at(cc.value + r.cig_off, r.n_cigar)
+            ln = np.frombuffer(C.string_at(cl.value + 4 * r.cig_off, 4 * r.n_cigar), dtype=np.int32)
+            cig = "".join("%d%s" % (int(l), chr(c)) for l, c in zip(ln, ch))
+        out.append((r.ret, r.dpScore, r.editDist, r.refB, r.refE, r.queryB, r.queryE, cig))
+    free_fn(cc)
+    free_fn(cl)
+    return out
+
+
+def dp_band_batch(variant, scores, tasks):
+    L = lib()
+    return dpband_call(L.alfa_dp_band_batch, variant, scores, tasks, L.alfa_free)
 
 
 def last_timing():

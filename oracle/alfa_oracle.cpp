@@ -549,6 +549,7 @@ extern "C" {
 
 void orc_counters_reset(void) { memset(&g_cnt, 0, sizeof(g_cnt)); }
 void orc_counters_get(orc_counters* out) { *out = g_cnt; }
+void orc_counters_add_dpband(int64_t cells) { g_cnt.cells_dpband += cells; }
 int64_t orc_sa_bytes(const orc_counters* c) {
     return 8 * c->kmr_reads + 4 * c->child_reads + c->lcp_reads + 4 * c->sa_reads + c->s_bytes + c->p_bytes + 16 * c->matches;
 }

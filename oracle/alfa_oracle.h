@@ -51,8 +51,13 @@ int orc_ksw_extend_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, 
 int orc_ksw_nw_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, int32_t* score);
 int orc_ksw_global_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, int32_t* score,
                          uint32_t** cigar, int32_t* n_cigar, int64_t* cig_off);
+/* dynProg (dp_oracle.cpp).  r[k].ret: 0/1 = the reference's return value, 2 = the reference reads a matrix cell it never
+ * wrote (result undefined), 3 = the reference prints "Error in dynamic programming" and exits.  Returns -22 for arguments
+ * the reference asserts on or indexes out of bounds with (orc_dp_band_check). */
 int orc_dp_band_batch(int variant, const alfa_dpband_scores* s, const alfa_dpband_task* t, int n,
                       alfa_dpband_result* r, char** cig_chars, int32_t** cig_lens);
+int orc_dp_band_check(int variant, const alfa_dpband_scores* s, const alfa_dpband_task* t);
+void orc_counters_add_dpband(int64_t cells);
 void orc_free(void*);
 
 #ifdef __cplusplus

@@ -57,3 +57,62 @@ def mapper_like_tasks(seed, n, read_len=250, err=0.02, band=21):
         ws.append(min(band, ql))
         hs.append(int(rng.integers(20, read_len)))
     return pairs, ws, hs
+
+
+# ---------------------------------------------------------------- dynProg (dp.cpp) cases, SURVEY 8c item 2(iii)
+def dpband_valid_flags(variant):
+    """dp_type flag tuples (freeRefB, freeRefE, freeQueryB, freeQueryE, local) the variant accepts"""
+    out = []
+    for m in range(32):
+        f = tuple((m >> k) & 1 for k in range(5))
+        if variant == 0:        # dpBandStatic asserts: not local, no free begin together with a free end (src/dp.cpp:663-664)
+            if f[4] or ((f[0] or f[2]) and (f[1] or f[3])):
+                continue
+        out.append(f)
+    return out
+
+
+def dpband_cases(rng, n, variant, max_len=200, alphabet=b"acgt"):
+    """random (ref, query) pairs related by substitutions and indels, embedded in longer strings with boundaries"""
+    import numpy as np
+    flags = dpband_valid_flags(variant)
+    specs = []
+    for _ in range(n):
+        L = int(rng.integers(0, max_len + 1)) if rng.random() < 0.9 else int(rng.integers(0, 4))
+        a = bytes(rng.choice(np.frombuffer(alphabet, np.uint8), L))
+        b = bytearray()
+        err = rng.choice([0.0, 0.03, 0.1, 0.3])
+        for ch in a:
+            u = rng.random()
+            if u < err * 0.5:
+                b.append(alphabet[int(rng.integers(0, len(alphabet)))])
+            elif u < err * 0.75:
+                b.append(ch); b.append(alphabet[int(rng.integers(0, len(alphabet)))])
+            elif u < err:
+                pass
+            else:
+                b.append(ch)
+        if rng.random() < 0.15:       # unrelated tail / head so that free ends matter
+            b = bytearray(rng.choice(np.frombuffer(alphabet, np.uint8), int(rng.integers(0, 15)))) + b
+        if rng.random() < 0.15:
+            a = a + bytes(rng.choice(np.frombuffer(alphabet, np.uint8), int(rng.integers(0, 15))))
+        if rng.random() < 0.1:
+            b = bytearray(bytes(b).upper()) if rng.random() < 0.5 else b + b"n"
+        pr, pq = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        ref = b"t" * pr + a + b"g" * int(rng.integers(0, 4))
+        qry = b"c" * pq + bytes(b) + b"a" * int(rng.integers(0, 4))
+        sp = dict(ref=ref, query=qry, refB=pr, refE=pr + len(a) - 1, queryB=pq, queryE=pq + len(b) - 1,
+                  flags=flags[int(rng.integers(0, len(flags)))], out_type=int(rng.choice([0, 1, 3, 4])))
+        if variant == 0:
+            sp["band1"] = int(rng.choice([1, 2, 5, 10, 30]))
+            sp["band2"] = int(rng.choice([1, 10, 40, 300]))
+        else:
+            if rng.random() < 0.7:
+                sp["band1"] = sp["band2"] = int(rng.choice([1, 3, 10, 30]))
+            else:
+                sp["band1"], sp["band2"] = int(rng.choice([1, 3, 10, 30])), int(rng.choice([1, 3, 10, 30]))
+        specs.append(sp)
+    return specs
+
+
+DPBAND_SCORES = [(1, -4, -6, -1), (2, -2, -2, -2), (1, -1, 0, -1), (0, -2, 0, -2), (3, -5, -8, -3), (1, -3, 0, -2)]

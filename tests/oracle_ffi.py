@@ -195,3 +195,65 @@ def ref_ksw_global(params, q, t, w):
     if cg.value:
         L.ref_free(cg)
     return s, cig
+
+
+# ---------------------------------------------------------------- dynProg (dp.cpp)
+def orc_dp_band_batch(variant, scores, tasks):
+    L = oracle()
+
+    def chk(rc):
+        if rc:
+            raise ffi.AlfaError("oracle dp_band error %d" % rc)
+    old, ffi_check = ffi.check, None
+    try:
+        ffi.check = chk
+        return ffi.dpband_call(L.orc_dp_band_batch, variant, scores, tasks, L.orc_free)
+    finally:
+        ffi.check = old
+
+
+def ref_dynprog(variant, scores, spec):
+    """one call of the REAL reference class (dynProg, via oracle/ref_shim.cpp); same tuple as ffi.dpband_call.
+    The reference calls exit(1) on a failed traceback: run it in a forked child when that can happen."""
+    L = reflib()
+    r, q = spec["ref"], spec["query"]
+    f = [int(bool(x)) for x in spec.get("flags", (0, 0, 0, 0, 0))]
+    out = (C.c_long * 8)()
+    cap = len(r) + len(q) + 8
+    cc = C.create_string_buffer(cap)
+    cl = (C.c_int * cap)()
+    L.ref_dynprog(int(variant), int(scores.affine), scores.match, scores.mismatch, scores.openGap, scores.extendGap,
+                  r, C.c_long(len(r)), q, C.c_long(len(q)), C.c_long(spec.get("refB", 0)), C.c_long(spec.get("refE", len(r) - 1)),
+                  spec.get("queryB", 0), spec.get("queryE", len(q) - 1), f[0], f[1], f[2], f[3], f[4],
+                  spec.get("out_type", 4), spec.get("band1", 10), spec.get("band2", 10), out, cc, cl, cap)
+    n = int(out[7])
+    cig = "".join("%d%s" % (cl[i], chr(cc.raw[i])) for i in range(n))
+    return (int(out[0]), int(out[1]), int(out[2]), int(out[3]), int(out[4]), int(out[5]), int(out[6]), cig)
+
+
+def ref_dynprog_forked(variant, scores, spec):
+    """ref_dynprog in a child process; returns the tuple, or ("exit", status) when the reference ended the process"""
+    import pickle
+    rd, wr = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            os.close(rd)
+            devnull = os.open(os.devnull, os.O_WRONLY)
+            os.dup2(devnull, 2)
+            res = ref_dynprog(variant, scores, spec)
+            os.write(wr, pickle.dumps(res))
+        finally:
+            os._exit(0)
+    os.close(wr)
+    data = b""
+    while True:
+        chunk = os.read(rd, 65536)
+        if not chunk:
+            break
+        data += chunk
+    os.close(rd)
+    _, status = os.waitpid(pid, 0)
+    if not data:
+        return ("exit", status)
+    return pickle.loads(data)

@@ -43,3 +43,7 @@ def test_oracle_vs_live_reference_nochild_and_suflink():
             m, off = O.orc_seed_batch(mine.view, mt, q)
             for i, r in enumerate(reads):
                 assert np.array_equal(m[off[i]:off[i + 1]], rix.seed(mt, r, 30, 1000, 1, 10)), (K, suf, child, mt, i)
+
+
+def test_oracle_dynprog_vs_reference_goldens():
+    assert G.check_dpband(O.orc_dp_band_batch) > 1000
