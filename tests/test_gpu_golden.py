@@ -24,3 +24,7 @@ def test_gpu_ksw_vs_captured_mapper_calls(gpu):
 
 def test_gpu_ksw_vs_reference_edge_cases(gpu):
     assert G.check_ksw_random(ffi.ksw_extend_batch, ffi.ksw_nw_batch, ffi.ksw_global_batch) == 1500
+
+
+def test_gpu_dynprog_vs_reference_goldens(gpu):
+    assert G.check_dpband(ffi.dp_band_batch) > 1000
