@@ -23,6 +23,7 @@
 //     tasks, run in a scalar lane-per-task kernel that follows the reference loop
 //     literally (the rare tail; never the throughput path).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -43,6 +44,8 @@ struct DevTask {
     int32_t qlen, tlen, w, h0;
     int32_t orig;         // index in the caller's task array
     int32_t cigcap;       // GLOBAL: capacity of the CIGAR slot
+    int32_t cigcap2;      // GLOBAL, lane kernel with LDS: row stride (cells) of the wave's interleaved direction bytes
+    int32_t pad;
 };
 
 struct DevParams {
@@ -55,27 +58,36 @@ struct ExtOut { int32_t score, qle, tle, gtle, gscore, max_off; };
 // ---------------------------------------------------------------- wave primitives
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Cross-lane steps are DPP moves (ALU latency), not ds_bpermute round trips through the LDS crossbar: a row of the DP needs
+// ~30 of them back to back, and they are the critical path of the wave-per-task kernel.
+//   row_shr:n  lane i <- lane i-n inside its row of 16 (0x110+n)     wave_shr:1  lane i <- lane i-1 (0x138)
+//   row_bcast:15 / :31  last lane of the previous row / half -> next (0x142 / 0x143)   wave_shl:1  lane i <- lane i+1 (0x130)
+// Lanes without a source keep `old`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
+
+// inclusive prefix max across the 64 lanes
+__device__ __forceinline__ int wave_incl_max_scan(int v, int identity) {
+    v = max(v, dpp<0x111, 0xf>(identity, v));
+    v = max(v, dpp<0x112, 0xf>(identity, v));
+    v = max(v, dpp<0x114, 0xf>(identity, v));
+    v = max(v, dpp<0x118, 0xf>(identity, v));
+    v = max(v, dpp<0x142, 0xa>(identity, v));
+    v = max(v, dpp<0x143, 0xc>(identity, v));
+    return v;
+}
 // exclusive prefix max across the 64 lanes; lane 0 receives `identity`
 __device__ __forceinline__ int wave_excl_max_scan(int v, int identity) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int o = __shfl_up(v, off, 64);
-        if (lane >= off) v = max(v, o);
-    }
-    int ex = __shfl_up(v, 1, 64);
-    return lane == 0 ? identity : ex;
+    return dpp<0x138, 0xf>(identity, wave_incl_max_scan(v, (int)0x80000000));
 }
 __device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-    return v;
+    return __builtin_amdgcn_readlane(wave_incl_max_scan(v, (int)0x80000000), 63);
 }
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-    return v;
-}
+__device__ __forceinline__ int wave_min(int v) { return -wave_max(-v); }     // callers pass values > INT_MIN
+// value of lane `src` (wave-uniform index)
+__device__ __forceinline__ int lane_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+// lane i <- lane i+1; lane 63 <- fill
+__device__ __forceinline__ int wave_shift_down1(int v, int fill) { return dpp<0x130, 0xf>(fill, v); }
 
 __device__ __forceinline__ int score_of(uint64_t mr, uint32_t q) { return (int)(int8_t)(mr >> (8 * q)); }
 
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
                 int hv = Hrow[0];
 #pragma unroll
                 for (int c = 1; c < C; ++c) hv = (dl % C == c) ? Hrow[c] : hv;
-                h1 = __shfl(hv, dl / C, 64);
+                h1 = lane_bcast(hv, dl / C);
             }
             if (jfin == qlen) {                             // ksw.c:425-428
                 max_ie = gscore > h1 ? max_ie : i;
@@ -278,9 +290,8 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
 
         // ---- shift E and the query characters one diagonal down for the next row
         {
-            int e_up = __shfl_down(Eo[0], 1, 64);
-            uint32_t q_up = __shfl_down(qc[0], 1, 64);
-            if (lane == 63) { e_up = FLOOR; q_up = qfeed; }
+            const int e_up = wave_shift_down1(Eo[0], FLOOR);
+            const uint32_t q_up = (uint32_t)wave_shift_down1((int)qc[0], (int)qfeed);
 #pragma unroll
             for (int c = 0; c < C - 1; ++c) { E[c] = Eo[c + 1]; qc[c] = qc[c + 1]; }
             E[C - 1] = e_up;
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
             int hv = Hd[0];
 #pragma unroll
             for (int c = 1; c < C; ++c) hv = (dl % C == c) ? Hd[c] : hv;
-            score = __shfl(hv, dl / C, 64);
+            score = lane_bcast(hv, dl / C);
         }
         if (lane == 0) out[T.orig] = score;
     }
@@ -345,12 +356,31 @@ __global__ void ksw_backtrack_kernel(const DevTask* __restrict__ tasks, int ntas
     ncig[T.orig] = n;
 }
 
-// ---------------------------------------------------------------- generic scalar kernel (one lane per task)
-// Literal restatement of the reference loops for tasks outside the wave kernel's envelope.
-template <int MODE>
-__global__ void ksw_scalar_kernel(const DevTask* __restrict__ tasks, int ntask, const uint8_t* __restrict__ seq,
-                                  const DevParams* __restrict__ prm, int32_t* __restrict__ out, int2* __restrict__ ehbuf,
-                                  uint8_t* __restrict__ zbuf, uint32_t* __restrict__ cig, int32_t* __restrict__ ncig) {
+// ---------------------------------------------------------------- lane-per-task kernels
+// The reference loops (ksw.c:391-443, 491-522, 524-538) run literally, one task per lane.  Two storage policies:
+//   LDS=true   the throughput path for short tasks (the bulk of a short-read workload: queries of 20-100 residues):
+//              eh[] and the query of every lane live in LDS, interleaved by lane (entry j of lane l at [j*64+l]: one
+//              conflict-free ds_read_b64/ds_write_b64 per cell), direction bytes go to HBM interleaved the same way
+//              (coalesced per wave), and 64 independent tasks keep all lanes of the wave busy -- unlike the
+//              wave-per-task kernel, whose band of 2w+1 diagonals leaves most lanes idle on queries this short.
+//   LDS=false  generic fallback for tasks outside every other kernel's envelope (global-memory eh[], contiguous z).
+template <bool LDS>
+struct LaneStore {
+    int2* eh;            // LDS: base of the wave's interleaved array (+lane); global: this task's array
+    uint8_t* q;          // LDS: base of the wave's interleaved query bytes (+lane); global: unused
+    const uint8_t* qg;
+    __device__ __forceinline__ int2 get(int j) const { return LDS ? eh[j * 64] : eh[j]; }
+    __device__ __forceinline__ void set(int j, int2 v) { if (LDS) eh[j * 64] = v; else eh[j] = v; }
+    __device__ __forceinline__ int geth(int j) const { return LDS ? eh[j * 64].x : eh[j].x; }
+    __device__ __forceinline__ uint32_t qat(int j) const { return LDS ? q[j * 64] : qg[j]; }
+};
+
+template <int MODE, bool LDS>
+__global__ __launch_bounds__(64) void ksw_lane_kernel(const DevTask* __restrict__ tasks, int ntask, const uint8_t* __restrict__ seq,
+                                                     const DevParams* __restrict__ prm, int32_t* __restrict__ out, int2* __restrict__ ehbuf,
+                                                     uint8_t* __restrict__ zbuf, uint32_t* __restrict__ cig, int32_t* __restrict__ ncig,
+                                                     int qcap) {
+    extern __shared__ int2 lds_eh[];        // LDS: (qcap+2)*64 int2, then (qcap+1)*64 query bytes
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntask) return;
     const DevTask T = tasks[t];
@@ -359,28 +389,42 @@ __global__ void ksw_scalar_kernel(const DevTask* __restrict__ tasks, int ntask, 
     const int qlen = T.qlen, tlen = T.tlen;
     int w = T.w;
     const int gapo = prm->gapo, gape = prm->gape, gapoe = gapo + gape;
-    int2* eh = ehbuf + T.ehoff;   // .x = h, .y = e ; qlen+2 entries
+    LaneStore<LDS> st;
+    st.qg = q;
+    if (LDS) {
+        st.eh = lds_eh + threadIdx.x;
+        st.q = (uint8_t*)(lds_eh + (size_t)(qcap + 2) * 64) + threadIdx.x;
+        for (int j = 0; j < qlen; ++j) st.q[j * 64] = q[j];
+    } else {
+        st.eh = ehbuf + T.ehoff;   // .x = h, .y = e ; qlen+2 entries
+        st.q = nullptr;
+    }
+    // direction bytes: LDS policy -> cell c of this lane at z[c*64] (T.zoff already includes the lane), row stride T.cigcap2 cells
+    const int64_t zs = LDS ? 64 : 1;
     if (MODE == MODE_EXTEND) {
         int h0 = T.h0 < 0 ? 0 : T.h0;
-        for (int j = 0; j <= qlen + 1; ++j) eh[j] = make_int2(0, 0);
-        eh[0].x = h0;
-        eh[1].x = h0 > gapoe ? h0 - gapoe : 0;
-        for (int j = 2; j <= qlen && eh[j - 1].x > gape; ++j) eh[j].x = eh[j - 1].x - gape;
+        for (int j = 0; j <= qlen + 1; ++j) st.set(j, make_int2(0, 0));
+        st.set(0, make_int2(h0, 0));
+        { int prev = h0 > gapoe ? h0 - gapoe : 0; if (qlen + 1 >= 1) st.set(1, make_int2(prev, 0));
+          for (int j = 2; j <= qlen && prev > gape; ++j) { prev -= gape; st.set(j, make_int2(prev, 0)); } }
         int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
         int beg = 0, end = qlen;
+        uint32_t tnext = tlen > 0 ? tg[0] : 0u;
         for (int i = 0; i < tlen; ++i) {
             int f = 0, h1, m = 0, mj = -1, j;
-            const uint64_t mr = prm->matrow[tg[i]];
+            const uint64_t mr = prm->matrow[tnext];
+            if (i + 1 < tlen) tnext = tg[i + 1];
             h1 = h0 - (gapo + gape * (i + 1));
             if (h1 < 0) h1 = 0;
             if (beg < i - w) beg = i - w;
             if (end > i + w + 1) end = i + w + 1;
             if (end > qlen) end = qlen;
+            int2 p = beg < end ? st.get(beg) : make_int2(0, 0);
             for (j = beg; j < end; ++j) {
-                int2 p = eh[j];
+                const int2 pn = st.get(j + 1);           // next cell's state: independent of this iteration's store
                 int h = p.x, e = p.y;
                 p.x = h1;
-                h += score_of(mr, q[j]);
+                h += score_of(mr, st.qat(j));
                 h = h > e ? h : e;
                 h = h > f ? h : f;
                 h1 = h;
@@ -391,11 +435,12 @@ __global__ void ksw_scalar_kernel(const DevTask* __restrict__ tasks, int ntask, 
                 e -= gape;
                 e = e > h ? e : h;
                 p.y = e;
-                eh[j] = p;
+                st.set(j, p);
                 f -= gape;
                 f = f > h ? f : h;
+                p = pn;
             }
-            eh[end] = make_int2(h1, 0);
+            st.set(end, make_int2(h1, 0));
             if (j == qlen) {
                 max_ie = gscore > h1 ? max_ie : i;
                 gscore = gscore > h1 ? gscore : h1;
@@ -408,32 +453,35 @@ __global__ void ksw_scalar_kernel(const DevTask* __restrict__ tasks, int ntask, 
                 int off = mj - i; off = off < 0 ? -off : off;
                 max_off = max_off > off ? max_off : off;
             }
-            for (j = mj; j >= beg && eh[j].x; --j) {}
+            for (j = mj; j >= beg && st.geth(j); --j) {}
             beg = j + 1;
-            for (j = mj + 2; j <= end && eh[j].x; ++j) {}
+            for (j = mj + 2; j <= end && st.geth(j); ++j) {}
             end = j;
         }
         ExtOut* o = (ExtOut*)out + T.orig;
         o->score = mx; o->qle = max_j + 1; o->tle = max_i + 1; o->gtle = max_ie + 1; o->gscore = gscore; o->max_off = max_off;
     } else {
-        const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+        const int n_col = LDS ? T.cigcap2 : (qlen < 2 * w + 1 ? qlen : 2 * w + 1);     // row stride of z, in cells
         uint8_t* z = zbuf + T.zoff;
-        eh[0] = make_int2(0, NEG_INF);
+        st.set(0, make_int2(0, NEG_INF));
         int j;
-        for (j = 1; j <= qlen && j <= w; ++j) eh[j] = make_int2(-(gapo + gape * j), NEG_INF);
-        for (; j <= qlen; ++j) eh[j] = make_int2(NEG_INF, NEG_INF);
+        for (j = 1; j <= qlen && j <= w; ++j) st.set(j, make_int2(-(gapo + gape * j), NEG_INF));
+        for (; j <= qlen; ++j) st.set(j, make_int2(NEG_INF, NEG_INF));
+        uint32_t tnext = tlen > 0 ? tg[0] : 0u;
         for (int i = 0; i < tlen; ++i) {
             int f = NEG_INF, h1;
-            const uint64_t mr = prm->matrow[tg[i]];
+            const uint64_t mr = prm->matrow[tnext];
+            if (i + 1 < tlen) tnext = tg[i + 1];
             const int beg = i > w ? i - w : 0;
             const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
             h1 = beg == 0 ? -(gapo + gape * (i + 1)) : NEG_INF;
+            int2 p = beg < end ? st.get(beg) : make_int2(0, 0);
             for (j = beg; j < end; ++j) {
-                int2 p = eh[j];
+                const int2 pn = st.get(j + 1);
                 int h = p.x, e = p.y;
                 uint32_t d;
                 p.x = h1;
-                h += score_of(mr, q[j]);
+                h += score_of(mr, st.qat(j));
                 d = h >= e ? 0u : 1u;
                 h = h >= e ? h : e;
                 d = h >= f ? d : 2u;
@@ -444,15 +492,16 @@ __global__ void ksw_scalar_kernel(const DevTask* __restrict__ tasks, int ntask, 
                 d |= e > h ? 4u : 0u;
                 e = e > h ? e : h;
                 p.y = e;
-                eh[j] = p;
+                st.set(j, p);
                 f -= gape;
                 d |= f > h ? 32u : 0u;
                 f = f > h ? f : h;
-                if (MODE == MODE_GLOBAL) z[(int64_t)i * n_col + (j - beg)] = (uint8_t)d;
+                if (MODE == MODE_GLOBAL) z[((int64_t)i * n_col + (j - beg)) * zs] = (uint8_t)d;
+                p = pn;
             }
-            eh[end] = make_int2(h1, NEG_INF);
+            st.set(end, make_int2(h1, NEG_INF));
         }
-        out[T.orig] = eh[qlen].x;
+        out[T.orig] = st.geth(qlen);
         if (MODE == MODE_GLOBAL) {
             uint32_t* slot = cig + T.cigoff;
             int pos = T.cigcap, n = 0;
@@ -465,7 +514,7 @@ __global__ void ksw_scalar_kernel(const DevTask* __restrict__ tasks, int ntask, 
             if (tlen > qlen + w) { ncig[T.orig] = -1; return; }
             int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0;
             while (i >= 0 && k >= 0) {
-                const uint32_t zv = z[(int64_t)i * n_col + (k - (i > w ? i - w : 0))];
+                const uint32_t zv = z[((int64_t)i * n_col + (k - (i > w ? i - w : 0))) * zs];
                 which = (zv >> (which << 1)) & 3;
                 if (which == 0) { push(0, 1); --i; --k; }
                 else if (which == 1) { push(2, 1); --i; }
@@ -487,7 +536,7 @@ struct alfa_dp_batch {
     DevParams hp;
     std::vector<DevTask> ht;        // device order, .orig already remapped to the dense output index
     std::vector<int> dense_of;      // device order -> caller index
-    int bin_cnt[4] = {0, 0, 0, 0};  // C=1, C=2, C=4, scalar
+    int bin_cnt[7] = {0, 0, 0, 0, 0, 0, 0};  // lane kernel (qlen <= 30, 62, 126), wave kernel C=1, 2, 4, generic lane kernel
     int64_t cig_words = 0, cells = 0, zbytes = 0, eh_items = 0;
     size_t seq_bytes = 0, out_bytes = 0;
     alfa::DevBuf d_seq, d_tasks, d_out, d_z, d_cig, d_eh;
@@ -556,21 +605,38 @@ void launch_all(alfa_dp_batch* b, hipStream_t st) {
     int32_t* d_ncig = MODE == MODE_GLOBAL ? (int32_t*)(d_cig + b->cig_words) : nullptr;
     const int* bc = b->bin_cnt;
     int o = 0;
-    launch_wave<MODE, 1>(st, d_t + o, bc[0], d_seq, d_prm, d_out, d_z);
-    if (MODE == MODE_GLOBAL && bc[0])
-        hipLaunchKernelGGL((ksw_backtrack_kernel<1>), dim3((bc[0] + 63) / 64), dim3(64), 0, st, d_t + o, bc[0], d_z, d_cig, d_ncig);
-    o += bc[0];
-    launch_wave<MODE, 2>(st, d_t + o, bc[1], d_seq, d_prm, d_out, d_z);
-    if (MODE == MODE_GLOBAL && bc[1])
-        hipLaunchKernelGGL((ksw_backtrack_kernel<2>), dim3((bc[1] + 63) / 64), dim3(64), 0, st, d_t + o, bc[1], d_z, d_cig, d_ncig);
-    o += bc[1];
-    launch_wave<MODE, 4>(st, d_t + o, bc[2], d_seq, d_prm, d_out, d_z);
-    if (MODE == MODE_GLOBAL && bc[2])
-        hipLaunchKernelGGL((ksw_backtrack_kernel<4>), dim3((bc[2] + 63) / 64), dim3(64), 0, st, d_t + o, bc[2], d_z, d_cig, d_ncig);
-    o += bc[2];
-    if (bc[3])
-        hipLaunchKernelGGL((ksw_scalar_kernel<MODE>), dim3((bc[3] + 63) / 64), dim3(64), 0, st, d_t + o, bc[3], d_seq, d_prm, d_out,
-                           b->d_eh.as<int2>(), d_z, d_cig, d_ncig);
+    // short queries: lane-per-task with LDS-resident state
+    static const int QCAP[3] = {30, 62, 126};
+    for (int k = 0; k < 3; ++k) {
+        if (bc[k]) {
+            const size_t lds = (size_t)(QCAP[k] + 2) * 64 * sizeof(int2) + (size_t)(QCAP[k] + 1) * 64;
+            if (lds > 48 * 1024) {
+                static bool raised[64] = {false};
+                if (!raised[b->device & 63]) {
+                    (void)hipFuncSetAttribute((const void*)ksw_lane_kernel<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                    raised[b->device & 63] = true;
+                }
+            }
+            hipLaunchKernelGGL((ksw_lane_kernel<MODE, true>), dim3((bc[k] + 63) / 64), dim3(64), lds, st, d_t + o, bc[k], d_seq, d_prm, d_out,
+                               (int2*)nullptr, d_z, d_cig, d_ncig, QCAP[k]);
+        }
+        o += bc[k];
+    }
+    launch_wave<MODE, 1>(st, d_t + o, bc[3], d_seq, d_prm, d_out, d_z);
+    if (MODE == MODE_GLOBAL && bc[3])
+        hipLaunchKernelGGL((ksw_backtrack_kernel<1>), dim3((bc[3] + 63) / 64), dim3(64), 0, st, d_t + o, bc[3], d_z, d_cig, d_ncig);
+    o += bc[3];
+    launch_wave<MODE, 2>(st, d_t + o, bc[4], d_seq, d_prm, d_out, d_z);
+    if (MODE == MODE_GLOBAL && bc[4])
+        hipLaunchKernelGGL((ksw_backtrack_kernel<2>), dim3((bc[4] + 63) / 64), dim3(64), 0, st, d_t + o, bc[4], d_z, d_cig, d_ncig);
+    o += bc[4];
+    launch_wave<MODE, 4>(st, d_t + o, bc[5], d_seq, d_prm, d_out, d_z);
+    if (MODE == MODE_GLOBAL && bc[5])
+        hipLaunchKernelGGL((ksw_backtrack_kernel<4>), dim3((bc[5] + 63) / 64), dim3(64), 0, st, d_t + o, bc[5], d_z, d_cig, d_ncig);
+    o += bc[5];
+    if (bc[6])
+        hipLaunchKernelGGL((ksw_lane_kernel<MODE, false>), dim3((bc[6] + 63) / 64), dim3(64), 0, st, d_t + o, bc[6], d_seq, d_prm, d_out,
+                           b->d_eh.as<int2>(), d_z, d_cig, d_ncig, 0);
 }
 
 // (re)fills `b` for tasks ids[] of t[]; buffers of `b` are reused when large enough
@@ -579,31 +645,41 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
     if (rc) return rc;
     b->mode = mode; b->n = n; b->device = cx->device; b->launched = false; b->kernel_ms = 0;
     b->cig_words = b->cells = b->zbytes = b->eh_items = 0;
-    for (int k = 0; k < 4; ++k) b->bin_cnt[k] = 0;
+    for (int k = 0; k < 7; ++k) b->bin_cnt[k] = 0;
     b->ht.resize((size_t)n);
     b->dense_of.resize((size_t)n);
     if (!b->ev0) { ALFA_HIP(hipEventCreate(&b->ev0)); ALFA_HIP(hipEventCreate(&b->ev1)); }
     if (n == 0) return ALFA_OK;
     std::vector<int> w_eff((size_t)n), bins((size_t)n), perm((size_t)n);
     size_t seq_bytes = 0;
+    // tasks of at most this many inner-loop iterations go to the lane-per-task kernel (0 = none); a lane runs its task
+    // serially, so the bound caps the kernel's critical path
+    static const int64_t lane_work = getenv("ALFA_DP_LANE_WORK") ? atoll(getenv("ALFA_DP_LANE_WORK")) : 0;
     for (int i = 0; i < n; ++i) {
         const alfa_dp_task& x = t[ids ? ids[i] : i];
         if (x.qlen < 0 || x.tlen < 0 || x.w < 0) return alfa::fail(ALFA_EINVAL, "negative length or band in a DP task");
         if ((x.qlen > 0 && !x.query) || (x.tlen > 0 && !x.target)) return alfa::fail(ALFA_EINVAL, "null sequence pointer in a DP task");
         w_eff[i] = effective_w(mode, p, x);
         int bin;
-        if (x.qlen == 0 || x.tlen == 0) bin = 3;
-        else { const int W = 2 * w_eff[i] + 1; bin = W <= 64 ? 0 : W <= 128 ? 1 : W <= 256 ? 2 : 3; }
+        if (x.qlen == 0 || x.tlen == 0) bin = 6;
+        else if (lane_work > 0 && x.qlen <= 126 && (int64_t)x.tlen * std::min<int64_t>(x.qlen, 2 * (int64_t)w_eff[i] + 1) <= lane_work)
+            bin = x.qlen <= 30 ? 0 : x.qlen <= 62 ? 1 : 2;
+        else { const int W = 2 * w_eff[i] + 1; bin = W <= 64 ? 3 : W <= 128 ? 4 : W <= 256 ? 5 : 6; }
         bins[i] = bin;
         b->bin_cnt[bin]++;
         seq_bytes += (size_t)x.qlen + (size_t)x.tlen;
     }
-    // order: by bin, longest targets first so that co-resident waves retire together
+    // order: by bin; inside a bin the most work first, so that the 64 tasks of a lane-kernel wave (and co-resident waves of the
+    // wave kernel) are alike and retire together
     std::iota(perm.begin(), perm.end(), 0);
+    std::vector<int64_t> work((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const alfa_dp_task& x = t[ids ? ids[i] : i];
+        work[i] = bins[i] < 3 ? (int64_t)x.tlen * std::min<int64_t>(x.qlen, 2 * (int64_t)w_eff[i] + 1) : (int64_t)x.tlen;
+    }
     std::sort(perm.begin(), perm.end(), [&](int a, int c) {
         if (bins[a] != bins[c]) return bins[a] < bins[c];
-        const int ta = t[ids ? ids[a] : a].tlen, tc = t[ids ? ids[c] : c].tlen;
-        if (ta != tc) return ta > tc;
+        if (work[a] != work[c]) return work[a] > work[c];
         return a < c;
     });
     b->seq_bytes = seq_bytes;
@@ -615,8 +691,12 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
     DevTask* ht = (DevTask*)(hprm + 1);
     *hprm = b->hp;
     size_t so = 0;
-    const int Cs[4] = {1, 2, 4, 0};
+    const int Cs[7] = {0, 0, 0, 1, 2, 4, 0};
     const int m = b->hp.m;
+    int bin_start[8] = {0};
+    for (int k = 0; k < 7; ++k) bin_start[k + 1] = bin_start[k] + b->bin_cnt[k];
+    int64_t wave_zbase = 0;
+    int wave_nc = 0;
     for (int k = 0; k < n; ++k) {
         const int li = perm[k];
         const int id = ids ? ids[li] : li;
@@ -631,12 +711,31 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         so += (size_t)x.tlen;
         d.qlen = x.qlen; d.tlen = x.tlen; d.w = w_eff[li]; d.h0 = x.h0; d.orig = k;
         b->dense_of[k] = li;
-        if (bins[li] == 3) { d.ehoff = b->eh_items; b->eh_items += (int64_t)x.qlen + 2; }
+        if (bins[li] == 6) { d.ehoff = b->eh_items; b->eh_items += (int64_t)x.qlen + 2; }
         if (mode == MODE_GLOBAL) {
-            d.zoff = b->zbytes;
-            if (bins[li] == 3) b->zbytes += std::min<int64_t>(x.qlen, 2 * (int64_t)d.w + 1) * x.tlen;
-            else b->zbytes += (int64_t)x.tlen * 64 * Cs[bins[li]];
-            b->zbytes = (b->zbytes + 15) & ~(int64_t)15;
+            if (bins[li] < 3) {
+                // lane kernel: the 64 tasks of a wave share one interleaved direction-byte region
+                const int in_bin = k - bin_start[bins[li]];
+                if ((in_bin & 63) == 0) {
+                    int64_t nc = 1, tl = 1;
+                    for (int kk = k; kk < std::min(k + 64, bin_start[bins[li] + 1]); ++kk) {
+                        const int l2 = perm[kk];
+                        const alfa_dp_task& y = t[ids ? ids[l2] : l2];
+                        nc = std::max<int64_t>(nc, std::min<int64_t>(y.qlen, 2 * (int64_t)w_eff[l2] + 1));
+                        tl = std::max<int64_t>(tl, y.tlen);
+                    }
+                    wave_zbase = b->zbytes;
+                    wave_nc = (int)nc;
+                    b->zbytes += nc * tl * 64;
+                }
+                d.zoff = wave_zbase + (in_bin & 63);
+                d.cigcap2 = wave_nc;
+            } else {
+                d.zoff = b->zbytes;
+                if (bins[li] == 6) b->zbytes += std::min<int64_t>(x.qlen, 2 * (int64_t)d.w + 1) * x.tlen;
+                else b->zbytes += (int64_t)x.tlen * 64 * Cs[bins[li]];
+                b->zbytes = (b->zbytes + 15) & ~(int64_t)15;
+            }
             d.cigoff = b->cig_words;
             d.cigcap = x.qlen + x.tlen + 2;
             b->cig_words += d.cigcap;
