@@ -318,16 +318,274 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
     }
 }
 
+// ---------------------------------------------------------------- group kernel: 16 lanes per task, 4 tasks per wavefront
+// Short-read tasks have bands of 10-60 diagonals and 20-50 columns: one task per 64-lane wave leaves most lanes idle and
+// the kernel is bound by the instructions issued per row.  Here a DPP row (16 lanes) owns a task -- same band-diagonal
+// layout and exact max-plus scan as above with C = 1, 2 or 4 diagonals per lane (bands up to 16, 32, 64 diagonals) -- so
+// one instruction stream advances four tasks, and every cross-lane step stays inside a row (row_shr / row_shl / row_ror).
+// What was wave-uniform above (band limits, maxima, the Z-drop exit) is row-uniform here and kept per lane.
+constexpr int GL = 16;                // lanes per task
+constexpr int GPW = 64 / GL;          // tasks per wavefront
+
+__device__ __forceinline__ int row_excl_max_scan(int v, int identity) {
+    constexpr int NEG = (int)0x80000000;
+    v = max(v, dpp<0x111, 0xf>(NEG, v));
+    v = max(v, dpp<0x112, 0xf>(NEG, v));
+    v = max(v, dpp<0x114, 0xf>(NEG, v));
+    v = max(v, dpp<0x118, 0xf>(NEG, v));
+    return dpp<0x111, 0xf>(identity, v);
+}
+// maximum over the 16 lanes of the row, in every lane (rotations: max is idempotent)
+__device__ __forceinline__ int row_max(int v) {
+    v = max(v, dpp<0x128, 0xf>(v, v));
+    v = max(v, dpp<0x124, 0xf>(v, v));
+    v = max(v, dpp<0x122, 0xf>(v, v));
+    v = max(v, dpp<0x121, 0xf>(v, v));
+    return v;
+}
+__device__ __forceinline__ int row_min(int v) { return -row_max(-v); }
+// lane i <- lane i+1 of its row; the row's last lane <- fill
+__device__ __forceinline__ int row_shift_down1(int v, int fill) { return dpp<0x101, 0xf>(fill, v); }
+
+template <int MODE, int C>
+__global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __restrict__ tasks, int ntask,
+                                                            const uint8_t* __restrict__ seq,
+                                                            const DevParams* __restrict__ prm,
+                                                            int32_t* __restrict__ out, uint8_t* __restrict__ zbuf) {
+    __shared__ uint64_t s_mat[8];
+    if (threadIdx.x < 8) s_mat[threadIdx.x] = prm->matrow[threadIdx.x];
+    __syncthreads();
+    const int lane = lane_id();
+    const int gl = lane & (GL - 1);
+    const int task = (blockIdx.x * WPB + (threadIdx.x >> 6)) * GPW + (lane >> 4);
+    const bool valid = task < ntask;
+    const DevTask T = tasks[valid ? task : ntask - 1];
+    const uint8_t* __restrict__ q = seq + T.qoff;
+    const uint8_t* __restrict__ tg = seq + T.toff;
+    const int qlen = T.qlen, tlen = valid ? T.tlen : 0, w = T.w;
+    const int gapo = prm->gapo, gape = prm->gape, gapoe = gapo + gape;
+    const int zdrop = prm->zdrop;
+    constexpr int FLOOR = (MODE == MODE_EXTEND) ? 0 : NEG_INF;
+    constexpr int ROWB = GL * C;      // direction bytes per row of one task
+
+    int Hd[C], E[C];
+    uint32_t qc[C];
+    int h0 = T.h0;
+    if (MODE == MODE_EXTEND && h0 < 0) h0 = 0;
+    const int eh1 = h0 > gapoe ? h0 - gapoe : 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int d = gl * C + c;
+        const int j = d - w;
+        qc[c] = (j >= 0 && j < qlen) ? q[j] : 0u;
+        if (MODE == MODE_EXTEND) {
+            int v = 0;
+            if (j == 0) v = h0;
+            else if (j > 0) { v = eh1 - (j - 1) * gape; v = v > 0 ? v : 0; }
+            Hd[c] = v;
+            E[c] = 0;
+        } else {
+            int v = NEG_INF;
+            if (j == 0) v = 0;
+            else if (j > 0 && j <= w && j <= qlen) v = -(gapo + gape * j);
+            Hd[c] = v;
+            E[c] = NEG_INF;
+        }
+    }
+
+    int beg = 0, end = qlen;
+    int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+    bool done = false;
+    // rows run to the longest of the wave's four targets
+    int tmax = tlen;
+    tmax = max(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = max(tmax, __shfl_xor(tmax, 32, 64));
+    uint32_t tnext = tlen > 0 ? tg[0] : 0u;           // target residue of row i, fetched one row ahead
+    uint64_t mr = s_mat[tnext & 7];
+    tnext = tlen > 1 ? tg[1] : 0u;
+
+    for (int i = 0; i < tmax; ++i) {
+        const bool live = !done && i < tlen;
+        const uint64_t mr_next = s_mat[tnext & 7];
+        const uint32_t tnext2 = i + 2 < tlen ? tg[i + 2] : 0u;
+        const int xq = i + 1 - w + ROWB - 1;
+        const uint32_t qfeed = (xq >= 0 && xq < qlen) ? q[xq] : 0u;
+
+        if (MODE == MODE_EXTEND) {
+            if (beg < i - w) beg = i - w;
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+        } else {
+            beg = i > w ? i - w : 0;
+            end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        }
+        const int base = i - w;
+        const int db = beg - base, de = end - base;
+
+        int A[C], Bv[C];
+        bool act[C];
+        uint32_t dirH[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int d = gl * C + c;
+            act[c] = live && d >= db && d < de;
+            const int hh = Hd[c] + score_of(mr, qc[c]);
+            const int e = E[c];
+            if (MODE == MODE_EXTEND) { A[c] = hh > e ? hh : e; dirH[c] = 0; }
+            else { dirH[c] = hh >= e ? 0u : 1u; A[c] = hh >= e ? hh : e; }
+            int bv = A[c] - gapoe;
+            if (MODE == MODE_EXTEND) bv = bv > 0 ? bv : 0;
+            Bv[c] = act[c] ? bv : FLOOR;
+        }
+        int L = Bv[0];
+#pragma unroll
+        for (int c = 1; c < C; ++c) L = max(L - gape, Bv[c]);
+        const int Cg = C * gape;
+        const int gx = row_excl_max_scan(L + gl * Cg, 0);
+        int f = gl == 0 ? FLOOR : gx - (gl - 1) * Cg;
+
+        int Hrow[C], Eo[C];
+        uint32_t zpack = 0;
+        int m_l = -1, mj_l = -1;
+        int zl_l = -1, zr_l = 0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int F = f;
+            int h = A[c];
+            uint32_t dd = dirH[c];
+            if (MODE == MODE_EXTEND) { h = h > F ? h : F; }
+            else { if (!(h >= F)) { dd = 2u; h = F; } }
+            Hrow[c] = h;
+            int t = h - gapoe;
+            if (MODE == MODE_EXTEND) t = t > 0 ? t : 0;
+            const int e2 = E[c] - gape;
+            const int f2 = F - gape;
+            if (MODE == MODE_GLOBAL) {
+                dd |= (e2 > t) ? 4u : 0u;
+                dd |= (f2 > t) ? 32u : 0u;
+                zpack |= (act[c] ? dd : 0u) << (8 * c);
+            }
+            Eo[c] = act[c] ? (e2 > t ? e2 : t) : (live ? FLOOR : E[c]);
+            const int tt = act[c] ? t : FLOOR;
+            f = f2 > tt ? f2 : tt;
+            if (act[c]) Hd[c] = h;
+            if (MODE == MODE_EXTEND && act[c]) {
+                if (h >= m_l) { m_l = h; mj_l = base + gl * C + c; }
+            }
+        }
+        if (MODE == MODE_GLOBAL && live) {
+            uint8_t* zr = zbuf + T.zoff + (int64_t)i * ROWB + gl * C;
+            if (C == 4) *(uint32_t*)zr = zpack;
+            else if (C == 2) *(uint16_t*)zr = (uint16_t)zpack;
+            else *zr = (uint8_t)zpack;
+        }
+
+        if (MODE == MODE_EXTEND) {
+            const int m = row_max(m_l);
+            const int mj = row_max(m_l == m ? mj_l : -1);
+            const bool empty = !(beg < end);
+            const int jfin = empty ? beg : end;
+            int h1 = h0 - (gapo + gape * (i + 1));
+            if (h1 < 0) h1 = 0;
+            const int h1_init = h1;
+            if (!empty) {
+                // H(i,end-1): the value the reference leaves in h1 (all values are >= 0 here)
+                const int dl = end - 1 - base;
+                int hv = -1;
+#pragma unroll
+                for (int c = 0; c < C; ++c) hv = (gl * C + c == dl) ? Hrow[c] : hv;
+                h1 = row_max(hv);
+            }
+            int zl = -1, zr = 0x7fffffff;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int j = base + gl * C + c;
+                const int mjrow_l = m < 0 ? -1 : mj;
+                if (act[c] && Hrow[c] == 0) {
+                    if (j <= mjrow_l - 1) zl_l = j;
+                    if (j >= mjrow_l + 1 && j < zr_l) zr_l = j;
+                }
+            }
+            zl = row_max(zl_l);
+            zr = row_min(zr_l);
+            if (live) {
+                if (jfin == qlen) {
+                    max_ie = gscore > h1 ? max_ie : i;
+                    gscore = gscore > h1 ? gscore : h1;
+                }
+                const int mrow = m < 0 ? 0 : m;
+                const int mjrow = m < 0 ? -1 : mj;
+                int dlt = (i - max_i) - (jfin - max_j);
+                dlt = dlt < 0 ? -dlt : dlt;
+                if (mrow == 0 || (zdrop > 0 && mx - mrow - dlt * gape > zdrop)) done = true;     // ksw.c:429
+                else {
+                    if (mrow > mx) {
+                        mx = mrow; max_i = i; max_j = mjrow;
+                        int off = mjrow - i; off = off < 0 ? -off : off;
+                        max_off = max_off > off ? max_off : off;
+                    }
+                    const int di = db - 1;
+                    if (di >= 0) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+                            if (gl * C + c == di) Hd[c] = h1_init;
+                    }
+                    int nbeg;
+                    if (zl >= 0) nbeg = zl + 2;
+                    else if (h1_init == 0) nbeg = beg + 1;
+                    else nbeg = beg;
+                    beg = nbeg;
+                    end = (zr != 0x7fffffff) ? zr + 1 : end + 1;
+                }
+            }
+        } else if (live) {
+            const int di = w - i - 1;
+            if (di >= 0) {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (gl * C + c == di) Hd[c] = -(gapo + gape * (i + 1));
+            }
+        }
+
+        // shift E and the query characters one diagonal down for the next row (rows that are over keep their state)
+        {
+            const int e_up = row_shift_down1(Eo[0], FLOOR);
+            const uint32_t q_up = (uint32_t)row_shift_down1((int)qc[0], (int)qfeed);
+            if (live) {
+#pragma unroll
+                for (int c = 0; c < C - 1; ++c) { E[c] = Eo[c + 1]; qc[c] = qc[c + 1]; }
+                E[C - 1] = e_up;
+                qc[C - 1] = q_up;
+            }
+        }
+        mr = mr_next;
+        tnext = tnext2;
+    }
+
+    if (!valid) return;
+    if (MODE == MODE_EXTEND) {
+        if (gl == 0) {
+            ExtOut* o = (ExtOut*)out + T.orig;
+            o->score = mx; o->qle = max_j + 1; o->tle = max_i + 1; o->gtle = max_ie + 1; o->gscore = gscore; o->max_off = max_off;
+        }
+    } else {
+        const int dl = qlen - tlen + w;
+        int hv = (int)0x80000000;
+#pragma unroll
+        for (int c = 0; c < C; ++c) hv = (gl * C + c == dl) ? Hd[c] : hv;
+        const int score = (dl >= 0 && dl <= 2 * w) ? row_max(hv) : NEG_INF;
+        if (gl == 0) out[T.orig] = score;
+    }
+}
+
 // ---------------------------------------------------------------- backtrack of the wave kernel's direction bytes
 // one lane per task; follows ksw.c:524-538 in band-diagonal coordinates.  CIGAR runs are written from the
 // end of the task's slot towards its start, so the slot tail holds the CIGAR already in forward order.
-template <int C>
 __global__ void ksw_backtrack_kernel(const DevTask* __restrict__ tasks, int ntask, const uint8_t* __restrict__ zbuf,
-                                     uint32_t* __restrict__ cig, int32_t* __restrict__ ncig) {
+                                     uint32_t* __restrict__ cig, int32_t* __restrict__ ncig, int ROWB) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntask) return;
     const DevTask T = tasks[t];
-    constexpr int ROWB = 64 * C;
     const int qlen = T.qlen, tlen = T.tlen, w = T.w;
     uint32_t* slot = cig + T.cigoff;
     int pos = T.cigcap;   // next free position is pos-1
@@ -536,7 +794,7 @@ struct alfa_dp_batch {
     DevParams hp;
     std::vector<DevTask> ht;        // device order, .orig already remapped to the dense output index
     std::vector<int> dense_of;      // device order -> caller index
-    int bin_cnt[7] = {0, 0, 0, 0, 0, 0, 0};  // lane kernel (qlen <= 30, 62, 126), wave kernel C=1, 2, 4, generic lane kernel
+    int bin_cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // lane kernel (qlen <= 30, 62, 126), group kernel C=1,2,4, wave kernel C=2,4, generic
     int64_t cig_words = 0, cells = 0, zbytes = 0, eh_items = 0;
     size_t seq_bytes = 0, out_bytes = 0;
     alfa::DevBuf d_seq, d_tasks, d_out, d_z, d_cig, d_eh;
@@ -594,6 +852,14 @@ void launch_wave(hipStream_t st, const DevTask* d_tasks, int n, const uint8_t* d
     hipLaunchKernelGGL((ksw_wave_kernel<MODE, C>), grid, block, 0, st, d_tasks, n, d_seq, d_prm, d_out, d_z);
 }
 
+template <int MODE, int C>
+void launch_group(hipStream_t st, const DevTask* d_tasks, int n, const uint8_t* d_seq, const DevParams* d_prm, int32_t* d_out, uint8_t* d_z) {
+    if (n <= 0) return;
+    const int per_block = WPB * GPW;
+    hipLaunchKernelGGL((ksw_group_kernel<MODE, C>), dim3((n + per_block - 1) / per_block), dim3(64 * WPB), 0, st, d_tasks, n, d_seq, d_prm,
+                       d_out, d_z);
+}
+
 template <int MODE>
 void launch_all(alfa_dp_batch* b, hipStream_t st) {
     const DevParams* d_prm = b->d_tasks.as<DevParams>();
@@ -622,20 +888,30 @@ void launch_all(alfa_dp_batch* b, hipStream_t st) {
         }
         o += bc[k];
     }
-    launch_wave<MODE, 1>(st, d_t + o, bc[3], d_seq, d_prm, d_out, d_z);
+    // bands of up to 16 / 32 / 64 diagonals: 16 lanes per task
+    launch_group<MODE, 1>(st, d_t + o, bc[3], d_seq, d_prm, d_out, d_z);
     if (MODE == MODE_GLOBAL && bc[3])
-        hipLaunchKernelGGL((ksw_backtrack_kernel<1>), dim3((bc[3] + 63) / 64), dim3(64), 0, st, d_t + o, bc[3], d_z, d_cig, d_ncig);
+        hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[3] + 63) / 64), dim3(64), 0, st, d_t + o, bc[3], d_z, d_cig, d_ncig, GL * 1);
     o += bc[3];
-    launch_wave<MODE, 2>(st, d_t + o, bc[4], d_seq, d_prm, d_out, d_z);
+    launch_group<MODE, 2>(st, d_t + o, bc[4], d_seq, d_prm, d_out, d_z);
     if (MODE == MODE_GLOBAL && bc[4])
-        hipLaunchKernelGGL((ksw_backtrack_kernel<2>), dim3((bc[4] + 63) / 64), dim3(64), 0, st, d_t + o, bc[4], d_z, d_cig, d_ncig);
+        hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[4] + 63) / 64), dim3(64), 0, st, d_t + o, bc[4], d_z, d_cig, d_ncig, GL * 2);
     o += bc[4];
-    launch_wave<MODE, 4>(st, d_t + o, bc[5], d_seq, d_prm, d_out, d_z);
+    launch_group<MODE, 4>(st, d_t + o, bc[5], d_seq, d_prm, d_out, d_z);
     if (MODE == MODE_GLOBAL && bc[5])
-        hipLaunchKernelGGL((ksw_backtrack_kernel<4>), dim3((bc[5] + 63) / 64), dim3(64), 0, st, d_t + o, bc[5], d_z, d_cig, d_ncig);
+        hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[5] + 63) / 64), dim3(64), 0, st, d_t + o, bc[5], d_z, d_cig, d_ncig, GL * 4);
     o += bc[5];
-    if (bc[6])
-        hipLaunchKernelGGL((ksw_lane_kernel<MODE, false>), dim3((bc[6] + 63) / 64), dim3(64), 0, st, d_t + o, bc[6], d_seq, d_prm, d_out,
+    // bands of up to 128 / 256 diagonals: a whole wavefront per task
+    launch_wave<MODE, 2>(st, d_t + o, bc[6], d_seq, d_prm, d_out, d_z);
+    if (MODE == MODE_GLOBAL && bc[6])
+        hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[6] + 63) / 64), dim3(64), 0, st, d_t + o, bc[6], d_z, d_cig, d_ncig, 64 * 2);
+    o += bc[6];
+    launch_wave<MODE, 4>(st, d_t + o, bc[7], d_seq, d_prm, d_out, d_z);
+    if (MODE == MODE_GLOBAL && bc[7])
+        hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[7] + 63) / 64), dim3(64), 0, st, d_t + o, bc[7], d_z, d_cig, d_ncig, 64 * 4);
+    o += bc[7];
+    if (bc[8])
+        hipLaunchKernelGGL((ksw_lane_kernel<MODE, false>), dim3((bc[8] + 63) / 64), dim3(64), 0, st, d_t + o, bc[8], d_seq, d_prm, d_out,
                            b->d_eh.as<int2>(), d_z, d_cig, d_ncig, 0);
 }
 
@@ -645,7 +921,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
     if (rc) return rc;
     b->mode = mode; b->n = n; b->device = cx->device; b->launched = false; b->kernel_ms = 0;
     b->cig_words = b->cells = b->zbytes = b->eh_items = 0;
-    for (int k = 0; k < 7; ++k) b->bin_cnt[k] = 0;
+    for (int k = 0; k < 9; ++k) b->bin_cnt[k] = 0;
     b->ht.resize((size_t)n);
     b->dense_of.resize((size_t)n);
     if (!b->ev0) { ALFA_HIP(hipEventCreate(&b->ev0)); ALFA_HIP(hipEventCreate(&b->ev1)); }
@@ -661,10 +937,10 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         if ((x.qlen > 0 && !x.query) || (x.tlen > 0 && !x.target)) return alfa::fail(ALFA_EINVAL, "null sequence pointer in a DP task");
         w_eff[i] = effective_w(mode, p, x);
         int bin;
-        if (x.qlen == 0 || x.tlen == 0) bin = 6;
+        if (x.qlen == 0 || x.tlen == 0) bin = 8;
         else if (lane_work > 0 && x.qlen <= 126 && (int64_t)x.tlen * std::min<int64_t>(x.qlen, 2 * (int64_t)w_eff[i] + 1) <= lane_work)
             bin = x.qlen <= 30 ? 0 : x.qlen <= 62 ? 1 : 2;
-        else { const int W = 2 * w_eff[i] + 1; bin = W <= 64 ? 3 : W <= 128 ? 4 : W <= 256 ? 5 : 6; }
+        else { const int W = 2 * w_eff[i] + 1; bin = W <= 16 ? 3 : W <= 32 ? 4 : W <= 64 ? 5 : W <= 128 ? 6 : W <= 256 ? 7 : 8; }
         bins[i] = bin;
         b->bin_cnt[bin]++;
         seq_bytes += (size_t)x.qlen + (size_t)x.tlen;
@@ -691,10 +967,10 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
     DevTask* ht = (DevTask*)(hprm + 1);
     *hprm = b->hp;
     size_t so = 0;
-    const int Cs[7] = {0, 0, 0, 1, 2, 4, 0};
+    const int rowb[9] = {0, 0, 0, GL * 1, GL * 2, GL * 4, 64 * 2, 64 * 4, 0};     // direction bytes per row
     const int m = b->hp.m;
-    int bin_start[8] = {0};
-    for (int k = 0; k < 7; ++k) bin_start[k + 1] = bin_start[k] + b->bin_cnt[k];
+    int bin_start[10] = {0};
+    for (int k = 0; k < 9; ++k) bin_start[k + 1] = bin_start[k] + b->bin_cnt[k];
     int64_t wave_zbase = 0;
     int wave_nc = 0;
     for (int k = 0; k < n; ++k) {
@@ -711,7 +987,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         so += (size_t)x.tlen;
         d.qlen = x.qlen; d.tlen = x.tlen; d.w = w_eff[li]; d.h0 = x.h0; d.orig = k;
         b->dense_of[k] = li;
-        if (bins[li] == 6) { d.ehoff = b->eh_items; b->eh_items += (int64_t)x.qlen + 2; }
+        if (bins[li] == 8) { d.ehoff = b->eh_items; b->eh_items += (int64_t)x.qlen + 2; }
         if (mode == MODE_GLOBAL) {
             if (bins[li] < 3) {
                 // lane kernel: the 64 tasks of a wave share one interleaved direction-byte region
@@ -732,8 +1008,8 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
                 d.cigcap2 = wave_nc;
             } else {
                 d.zoff = b->zbytes;
-                if (bins[li] == 6) b->zbytes += std::min<int64_t>(x.qlen, 2 * (int64_t)d.w + 1) * x.tlen;
-                else b->zbytes += (int64_t)x.tlen * 64 * Cs[bins[li]];
+                if (bins[li] == 8) b->zbytes += std::min<int64_t>(x.qlen, 2 * (int64_t)d.w + 1) * x.tlen;
+                else b->zbytes += (int64_t)x.tlen * rowb[bins[li]];
                 b->zbytes = (b->zbytes + 15) & ~(int64_t)15;
             }
             d.cigoff = b->cig_words;
