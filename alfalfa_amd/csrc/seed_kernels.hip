@@ -545,11 +545,65 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
                         }
                     }
                 }
-                if (alive && !done) traverse_from(X, P, prefix, start, end, depth, Q.plen, -1);
+                // Small multi-suffix hits (2..4 sampled suffixes share the 10-mer; nearly all multi hits of a non-repetitive
+                // reference).  The child-table descent reaches, by construction, the deepest match M of P[prefix..] among the
+                // suffixes of the interval and ends on the sub-interval of the suffixes that attain it (at a branching node when
+                // no child continues P, inside an edge on a mismatch, or at the end of the read).  With so few suffixes that is
+                // cheaper to evaluate directly: all SA entries, then all text chunks, are independent loads, instead of ~10
+                // dependent CHILD/LCP/SA/S probes.
+                int64_t sas[4];
+                bool small = false;
+                if (alive && !done && end - start < 4 && end > start) {
+                    small = true;
+                    const int nsuf = end - start + 1;
+                    const int c0 = prefix + KMER;
+                    int lim[4], mi[4];
+                    bool go[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sas[k] = k < nsuf ? (int64_t)X.SA[start + k] : 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        lim[k] = k < nsuf ? (int)max((int64_t)0, min((int64_t)(Q.plen - c0), X.N - (sas[k] + KMER))) : -1;
+                        mi[k] = lim[k] > 0 ? 0 : lim[k];          // -1 for unused slots
+                        go[k] = lim[k] > 0;
+                    }
+                    for (int off = 0; go[0] || go[1] || go[2] || go[3]; off += 16) {
+                        uint64_t a0[4], a1[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (go[k]) { a0[k] = ld8(X.S + sas[k] + KMER + off); a1[k] = ld8(X.S + sas[k] + KMER + off + 8); }
+                        const uint64_t b0 = P.load8(c0 + off), b1 = P.load8(c0 + off + 8);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (go[k]) {
+                                const uint64_t x0 = a0[k] ^ b0, x1 = a1[k] ^ b1;
+                                int m = 16;
+                                if (x0) m = __builtin_ctzll(x0) >> 3;
+                                else if (x1) m = 8 + (__builtin_ctzll(x1) >> 3);
+                                if (!(m >= 16 && lim[k] > off + 16)) { mi[k] = min(off + m, lim[k]); go[k] = false; }
+                            }
+                    }
+                    const int M = max(max(mi[0], mi[1]), max(mi[2], mi[3]));
+                    int ns = 3, ne = 0;
+#pragma unroll
+                    for (int k = 3; k >= 0; --k) if (mi[k] == M) ns = k;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (mi[k] == M) ne = k;
+                    depth = KMER + M;
+                    end = start + ne; start = start + ns;
+                    // keep the SA values of the surviving suffixes addressable by (rank - start)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) if (ns > k) { sas[0] = sas[1]; sas[1] = sas[2]; sas[2] = sas[3]; }
+                }
+                if (alive && !done && !small) traverse_from(X, P, prefix, start, end, depth, Q.plen, -1);
                 if (alive && depth > 1 && depth >= min_lenK && (end - start + 1) <= maxCount) {
                     int64_t mr; int mq, ml;
                     if (start == end && sa >= 0) cnt = lmax_strict(X, P, prefix, sa, depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
-                    else
+                    else if (small) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (k <= end - start) cnt += lmax_strict(X, P, prefix, sas[k], depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
+                    } else
                         for (int i = start; i <= end; ++i)
                             cnt += lmax_strict(X, P, prefix, (int64_t)X.SA[i], depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
                 }
