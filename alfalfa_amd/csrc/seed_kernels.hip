@@ -54,7 +54,7 @@ struct DIdx {
     const int32_t* __restrict__ Mval;
     const int32_t* __restrict__ CHILD;
     const uint2* __restrict__ KMR;      // the reference's 10-mer table {left, right}
-    const uint4* __restrict__ KMR2;     // derived at upload: {left, right, SA[left], S[SA[left]+10..+13]}: a single-suffix hit needs no SA / S probe
+    const uint4* __restrict__ KMR2;     // derived at upload: {left, right, SA[left], right == left ? S[SA[left]+10..+13] : SA[left+1]}
     const uint32_t* __restrict__ KBIT;  // derived at upload: bit per 10-mer, set when right > 0 (128 KiB: stays in L2)
     int64_t N;
     int32_t n, nM, K, has_kmer, has_child;
@@ -521,53 +521,50 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
             int cnt = 0, start = 0, end = X.n - 1, depth = 0, prefix = 0;
             if (t < Q.npref) {
                 prefix = pm.prefix_of(t);
-                int64_t sa = -1;
-                bool alive = true, done = false;
+                // Hits with 1..4 sampled suffixes behind the 10-mer (all but a fraction of a percent on a non-repetitive
+                // reference) are evaluated directly.  The child-table descent reaches, by construction, the deepest match M of
+                // P[prefix..] among the suffixes of the interval and ends on the sub-interval of the suffixes that attain it (at a
+                // branching node when no child continues P, inside an edge on a mismatch, or at the end of the read or text):
+                // with so few suffixes, M follows from comparing each of them with the read, all text chunks being independent
+                // loads (16 bytes per suffix and round trip) instead of ~10 dependent CHILD/LCP/SA/S probes.  A single suffix
+                // is the run of comparisons of :758,:781-786; its first 4 characters come with the table entry.
+                int64_t sas[4] = {0, 0, 0, 0};
+                int lim[4] = {-1, -1, -1, -1}, mi[4] = {-1, -1, -1, -1};     // -1: unused slot
+                bool go[4] = {false, false, false, false};
+                bool alive = true, direct = false;
+                int off0 = 0;
+                const int c0 = prefix + KMER;
                 if (use_kmer) {
                     const uint32_t index = kmer_code(P, prefix);
                     alive = index < TABLE && ((bits[index >> 5] >> (index & 31)) & 1u);
                     if (alive) {
                         const uint4 e = X.KMR2[index];
                         depth = KMER; start = (int)e.x; end = (int)e.y;
-                        if (start == end) {
-                            // single suffix: the run of comparisons of :758,:781-786, its first 4 characters from the table entry
-                            sa = (int64_t)e.z;
-                            const int c = prefix + KMER;
-                            const int64_t pos0 = sa + KMER;
-                            const int Ls = (int)max((int64_t)0, min((int64_t)(Q.plen - c), X.N - pos0));
-                            if (Ls > 0) {
-                                const uint32_t x = e.w ^ (uint32_t)P.load8(c);
+                        const int nsuf = end - start + 1;
+                        if (nsuf >= 1 && nsuf <= 4) {
+                            direct = true;
+                            sas[0] = (int64_t)e.z;
+                            if (nsuf >= 2) sas[1] = (int64_t)e.w;
+                            if (nsuf >= 3) sas[2] = (int64_t)X.SA[start + 2];
+                            if (nsuf >= 4) sas[3] = (int64_t)X.SA[start + 3];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (k < nsuf) {
+                                    lim[k] = (int)max((int64_t)0, min((int64_t)(Q.plen - c0), X.N - (sas[k] + KMER)));
+                                    mi[k] = 0;
+                                    go[k] = lim[k] > 0;
+                                }
+                            if (nsuf == 1 && go[0]) {
+                                const uint32_t x = e.w ^ (uint32_t)P.load8(c0);
                                 const int m4 = x ? (__builtin_ctz(x) >> 3) : 4;
-                                if (m4 < 4 || Ls <= 4) depth += min(m4, Ls);
-                                else depth += 4 + match_fwd(X, P, pos0 + 4, c + 4, Ls - 4);
+                                if (m4 < 4 || lim[0] <= 4) { mi[0] = min(m4, lim[0]); go[0] = false; }
+                                else off0 = 4;
                             }
-                            done = true;
                         }
                     }
                 }
-                // Small multi-suffix hits (2..4 sampled suffixes share the 10-mer; nearly all multi hits of a non-repetitive
-                // reference).  The child-table descent reaches, by construction, the deepest match M of P[prefix..] among the
-                // suffixes of the interval and ends on the sub-interval of the suffixes that attain it (at a branching node when
-                // no child continues P, inside an edge on a mismatch, or at the end of the read).  With so few suffixes that is
-                // cheaper to evaluate directly: all SA entries, then all text chunks, are independent loads, instead of ~10
-                // dependent CHILD/LCP/SA/S probes.
-                int64_t sas[4];
-                bool small = false;
-                if (alive && !done && end - start < 4 && end > start) {
-                    small = true;
-                    const int nsuf = end - start + 1;
-                    const int c0 = prefix + KMER;
-                    int lim[4], mi[4];
-                    bool go[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) sas[k] = k < nsuf ? (int64_t)X.SA[start + k] : 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        lim[k] = k < nsuf ? (int)max((int64_t)0, min((int64_t)(Q.plen - c0), X.N - (sas[k] + KMER))) : -1;
-                        mi[k] = lim[k] > 0 ? 0 : lim[k];          // -1 for unused slots
-                        go[k] = lim[k] > 0;
-                    }
-                    for (int off = 0; go[0] || go[1] || go[2] || go[3]; off += 16) {
+                if (direct) {
+                    for (int off = off0; go[0] || go[1] || go[2] || go[3]; off += 16) {
                         uint64_t a0[4], a1[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
@@ -594,12 +591,12 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
                     // keep the SA values of the surviving suffixes addressable by (rank - start)
 #pragma unroll
                     for (int k = 0; k < 3; ++k) if (ns > k) { sas[0] = sas[1]; sas[1] = sas[2]; sas[2] = sas[3]; }
+                } else if (alive) {
+                    traverse_from(X, P, prefix, start, end, depth, Q.plen, -1);
                 }
-                if (alive && !done && !small) traverse_from(X, P, prefix, start, end, depth, Q.plen, -1);
                 if (alive && depth > 1 && depth >= min_lenK && (end - start + 1) <= maxCount) {
                     int64_t mr; int mq, ml;
-                    if (start == end && sa >= 0) cnt = lmax_strict(X, P, prefix, sa, depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
-                    else if (small) {
+                    if (direct) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (k <= end - start) cnt += lmax_strict(X, P, prefix, sas[k], depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
@@ -1022,8 +1019,9 @@ int alfa_index_upload(const alfa_index_view* v, int device, alfa_index** out) {
         for (size_t i = 0; i < TABLE; ++i) {
             const uint32_t l = v->KMR[2 * i], r = v->KMR[2 * i + 1];
             const uint32_t sa = (l < (uint64_t)v->n) ? v->SA[l] : 0u;
-            uint32_t nxt = 0;        // S[sa+10 .. sa+13] (the host S carries 16 NUL bytes behind N)
-            if ((int64_t)sa + KMER + 4 <= v->N + 16) memcpy(&nxt, v->S + sa + KMER, 4);
+            uint32_t nxt = 0;        // one suffix: S[sa+10 .. sa+13] (the host S carries 16 NUL bytes behind N); more: SA[left+1]
+            if (r > l) nxt = (l + 1 < (uint64_t)v->n) ? v->SA[l + 1] : 0u;
+            else if ((int64_t)sa + KMER + 4 <= v->N + 16) memcpy(&nxt, v->S + sa + KMER, 4);
             k2[4 * i] = l; k2[4 * i + 1] = r; k2[4 * i + 2] = sa; k2[4 * i + 3] = nxt;
             if (r > 0) kb[i >> 5] |= 1u << (i & 31);
         }
