@@ -219,6 +219,18 @@ __device__ void traverse_from(const DIdx& X, const PatD& P, int prefix, int& sta
     }
 }
 
+// 10-mer code from the per-read array of 2-bit codes (one byte per residue, 0x80 = not ACGT / beyond the read), 8+2 bytes
+__device__ __forceinline__ uint32_t kmer_code_packed(const uint8_t* codes, int prefix) {
+    const uint64_t v = ld8(codes + prefix);
+    const uint32_t w = (uint32_t)ld8(codes + prefix + 8) & 0xffffu;
+    if ((v & 0x8080808080808080ull) | (w & 0x8080u)) return 0xFFFFFFFFu;
+    uint64_t x = __builtin_bswap64(v);                              // first residue -> most significant
+    x = (x | (x >> 6)) & 0x000F000F000F000Full;
+    x = (x | (x >> 12)) & 0x000000FF000000FFull;
+    x = (x | (x >> 24)) & 0xFFFFull;
+    return ((uint32_t)x << 4) | ((w & 0xffu) << 2) | (w >> 8);
+}
+
 __device__ __forceinline__ uint32_t kmer_code(const PatD& P, int prefix) {
     uint32_t index = 0;
 #pragma unroll
@@ -408,10 +420,22 @@ __device__ int collect_xmi_mli(const DIdx& X, const PAT& P, int prefix, IvalD ml
 // flat reference-order index t -> (phase k, step jj) of findSMAM's double loop
 struct PrefixMap {
     int step, nh, kh, Lmax;
+    uint32_t m1 = 0, m2 = 0;      // ceil(2^32 / nh), ceil(2^32 / (nh-1)): exact quotients for t, divisor < 2^16 (set_magic)
+    __device__ __forceinline__ void set_magic(int npref) {
+        m1 = m2 = 0;
+        if (npref < 65536 && nh >= 2 && nh < 65536) {
+            m1 = (uint32_t)((0x100000000ull + (uint32_t)nh - 1) / (uint32_t)nh);
+            m2 = nh >= 3 ? (uint32_t)((0x100000000ull + (uint32_t)(nh - 1) - 1) / (uint32_t)(nh - 1)) : 0;
+        }
+    }
     __device__ __forceinline__ int prefix_of(int t) const {
         int k, jj;
-        if (t < kh * nh) { k = t / nh; jj = t - k * nh; }
-        else { const int t2 = t - kh * nh; const int q = t2 / (nh - 1); k = kh + q; jj = t2 - q * (nh - 1); }
+        if (t < kh * nh) { k = m1 ? (int)__umulhi((uint32_t)t, m1) : t / nh; jj = t - k * nh; }
+        else {
+            const int t2 = t - kh * nh;
+            const int q = m2 ? (int)__umulhi((uint32_t)t2, m2) : t2 / (nh - 1);
+            k = kh + q; jj = t2 - q * (nh - 1);
+        }
         return k + jj * step;
     }
 };
@@ -486,14 +510,25 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
     __syncthreads();
     work += (size_t)blockIdx.x * seg_cap;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint8_t* mybuf = smem + KBIT_BYTES + (size_t)wid * lds_stride;
+    uint8_t* mybuf = smem + KBIT_BYTES + (size_t)wid * 2 * lds_stride;
     const int K = X.K;
     for (int r = blockIdx.x * PWAVES + wid; r < nq; r += gridDim.x * PWAVES) {      // wave-uniform
         const SeedQ Q = qs[r];
         PatD P;
         P.len = Q.plen;
-        if (Q.plen + 2 * PADB <= lds_stride) {
-            for (int i = lane; i < Q.plen; i += 64) mybuf[PADB + i] = reads[Q.poff + i];
+        const bool in_lds = Q.plen + 2 * PADB <= lds_stride;
+        uint8_t* codes = mybuf + lds_stride;                    // second half of the wave's slice: one 2-bit code per residue
+        if (in_lds) {
+            for (int i = lane; i < Q.plen + 16; i += 64) {
+                uint32_t cd = 0x80u;
+                if (i < Q.plen) {
+                    const uint32_t ch = reads[Q.poff + i];
+                    mybuf[PADB + i] = (uint8_t)ch;
+                    const uint32_t b = bitadd(ch);
+                    cd = b > 3u ? 0x80u : b;
+                }
+                codes[i] = (uint8_t)cd;
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -513,6 +548,7 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
             const int rr = pm.Lmax >= 0 ? pm.Lmax % step : 0;
             pm.kh = kk < rr + 1 ? kk : rr + 1;
         }
+        pm.set_magic(Q.npref);
         const int maxCount = Q.sparse_q * Q.max_count;
         const bool use_kmer = Q.plen >= KMER;                   // traverse_faster is called with min_len = |P| (:1073)
         int running = 0;
@@ -535,7 +571,7 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
                 int off0 = 0;
                 const int c0 = prefix + KMER;
                 if (use_kmer) {
-                    const uint32_t index = kmer_code(P, prefix);
+                    const uint32_t index = !in_lds ? kmer_code(P, prefix) : (prefix + KMER <= Q.plen ? kmer_code_packed(codes, prefix) : 0xFFFFFFFFu);
                     alive = index < TABLE && ((bits[index >> 5] >> (index & 31)) & 1u);
                     if (alive) {
                         const uint4 e = X.KMR2[index];
@@ -597,9 +633,10 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
                 if (alive && depth > 1 && depth >= min_lenK && (end - start + 1) <= maxCount) {
                     int64_t mr; int mq, ml;
                     if (direct) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (k <= end - start) cnt += lmax_strict(X, P, prefix, sas[k], depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
+                        for (int k = 0; k <= end - start; ++k) {
+                            const int64_t sk = k == 0 ? sas[0] : k == 1 ? sas[1] : k == 2 ? sas[2] : sas[3];
+                            cnt += lmax_strict(X, P, prefix, sk, depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
+                        }
                     } else
                         for (int i = start; i <= end; ++i)
                             cnt += lmax_strict(X, P, prefix, (int64_t)X.SA[i], depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
@@ -1143,7 +1180,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
             ncu = std::max(1, prop.multiProcessorCount);
         }
         pl->nseg = std::max(1, std::min(ncu, (nq + PWAVES - 1) / PWAVES));
-        const int room = (160 * 1024 - KBIT_BYTES - 1024) / PWAVES;                       // LDS bytes a wave can have for its read
+        const int room = (160 * 1024 - KBIT_BYTES - 1024) / PWAVES / 2;                   // LDS bytes a wave can have for its read (x2: codes)
         pl->stride = std::min(room & ~15, (max_plen + 2 * PADB + 15) & ~15);              // longer reads are read from global memory
     }
     const int64_t total_cap = std::min<int64_t>(std::max<int64_t>(4096, 4 * (int64_t)nq), std::max<int64_t>(total_pref, 1));
@@ -1178,7 +1215,7 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
     ALFA_HIP(hipEventRecord(pl->ev0, st));
     if (pl->persistent) {
         // one workgroup per CU, the 10-mer bitmap + one read slice per wave in LDS
-        const size_t lds = (size_t)KBIT_BYTES + (size_t)PWAVES * pl->stride;
+        const size_t lds = (size_t)KBIT_BYTES + (size_t)PWAVES * 2 * pl->stride;      // read bytes + 2-bit codes per wave
         hipLaunchKernelGGL(smam_count_kernel, dim3(pl->nseg), dim3(PBLOCK), lds, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec>(), d_cnt,
                            pl->seg_cap, nq, pl->stride);
     } else if (pl->mem_type == ALFA_SEED_SMAM) {
