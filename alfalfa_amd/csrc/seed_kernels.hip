@@ -66,6 +66,9 @@ struct SeedQ {          // one sparseSA::SMAM(P, ...) call
     int32_t npref;      // number of prefix queries of this call
     int32_t max_smem;   // max_smem_cont (SMEM only)
     int64_t soff;       // SMEM: offset (in ints) of this read's tables in the global scratch, when they do not fit in LDS
+    // findSMAM/findMEM prefix enumeration, precomputed on the host (wave-uniform divisions are not worth VALU time):
+    int32_t pm_nh, pm_kh;       // prefixes of the phases k < kh: nh each, of the others nh-1
+    uint32_t pm_m1, pm_m2;      // ceil(2^32/nh), ceil(2^32/(nh-1)) when the multiply-high quotient is exact, else 0
 };
 
 struct WorkRec2 {       // MEM / SMEM: one emitting prefix query with both of its intervals
@@ -421,13 +424,6 @@ __device__ int collect_xmi_mli(const DIdx& X, const PAT& P, int prefix, IvalD ml
 struct PrefixMap {
     int step, nh, kh, Lmax;
     uint32_t m1 = 0, m2 = 0;      // ceil(2^32 / nh), ceil(2^32 / (nh-1)): exact quotients for t, divisor < 2^16 (set_magic)
-    __device__ __forceinline__ void set_magic(int npref) {
-        m1 = m2 = 0;
-        if (npref < 65536 && nh >= 2 && nh < 65536) {
-            m1 = (uint32_t)((0x100000000ull + (uint32_t)nh - 1) / (uint32_t)nh);
-            m2 = nh >= 3 ? (uint32_t)((0x100000000ull + (uint32_t)(nh - 1) - 1) / (uint32_t)(nh - 1)) : 0;
-        }
-    }
     __device__ __forceinline__ int prefix_of(int t) const {
         int k, jj;
         if (t < kh * nh) { k = m1 ? (int)__umulhi((uint32_t)t, m1) : t / nh; jj = t - k * nh; }
@@ -542,13 +538,7 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
         PrefixMap pm;
         pm.step = step;
         pm.Lmax = Q.plen - min_lenK;
-        pm.nh = pm.Lmax >= 0 ? pm.Lmax / step + 1 : 0;
-        {
-            const int kk = K < pm.Lmax + 1 ? K : pm.Lmax + 1;
-            const int rr = pm.Lmax >= 0 ? pm.Lmax % step : 0;
-            pm.kh = kk < rr + 1 ? kk : rr + 1;
-        }
-        pm.set_magic(Q.npref);
+        pm.nh = Q.pm_nh; pm.kh = Q.pm_kh; pm.m1 = Q.pm_m1; pm.m2 = Q.pm_m2;
         const int maxCount = Q.sparse_q * Q.max_count;
         const bool use_kmer = Q.plen >= KMER;                   // traverse_faster is called with min_len = |P| (:1073)
         int running = 0;
@@ -1151,6 +1141,19 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
                                                       : count_prefixes(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q);
         if (np < 0 || np > 0x3fffffff) return alfa::fail(ALFA_EINVAL, "seed query has too many prefixes");
         s.npref = (int32_t)np;
+        {   // mirrors the device PrefixMap
+            const int64_t stp = (int64_t)q[i].sparse_q * ix->K;
+            const int64_t Lm = (int64_t)q[i].plen - (q[i].min_len - (stp - 1));
+            const int64_t nh = Lm >= 0 ? Lm / stp + 1 : 0;
+            const int64_t kk = std::min<int64_t>(ix->K, Lm + 1), rr = Lm >= 0 ? Lm % stp : 0;
+            s.pm_nh = (int32_t)nh;
+            s.pm_kh = (int32_t)std::min<int64_t>(kk, rr + 1);
+            s.pm_m1 = s.pm_m2 = 0;
+            if (np < 65536 && nh >= 2 && nh < 65536) {
+                s.pm_m1 = (uint32_t)((0x100000000ull + (uint64_t)nh - 1) / (uint64_t)nh);
+                if (nh >= 3) s.pm_m2 = (uint32_t)((0x100000000ull + (uint64_t)(nh - 1) - 1) / (uint64_t)(nh - 1));
+            }
+        }
         s.max_smem = q[i].max_smem_cont;
         s.soff = scr_ints;
         const int w = (int)std::max<int64_t>(q[i].plen, np) + 2;
