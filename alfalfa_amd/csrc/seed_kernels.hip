@@ -426,10 +426,17 @@ struct PrefixMap {
     uint32_t m1 = 0, m2 = 0;      // ceil(2^32 / nh), ceil(2^32 / (nh-1)): exact quotients for t, divisor < 2^16 (set_magic)
     __device__ __forceinline__ int prefix_of(int t) const {
         int k, jj;
-        if (t < kh * nh) { k = m1 ? (int)__umulhi((uint32_t)t, m1) : t / nh; jj = t - k * nh; }
+        if (t < kh * nh) { k = t / nh; jj = t - k * nh; }
+        else { const int t2 = t - kh * nh; const int q = t2 / (nh - 1); k = kh + q; jj = t2 - q * (nh - 1); }
+        return k + jj * step;
+    }
+    // same with the host's multiply-high constants: m1 == 0 means nh <= 1 (quotient = t), m2 == 0 means nh-1 <= 1
+    __device__ __forceinline__ int prefix_of_fast(int t) const {
+        int k, jj;
+        if (t < kh * nh) { k = m1 ? (int)__umulhi((uint32_t)t, m1) : t; jj = t - k * nh; }
         else {
             const int t2 = t - kh * nh;
-            const int q = m2 ? (int)__umulhi((uint32_t)t2, m2) : t2 / (nh - 1);
+            const int q = m2 ? (int)__umulhi((uint32_t)t2, m2) : t2;
             k = kh + q; jj = t2 - q * (nh - 1);
         }
         return k + jj * step;
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
             const int t = base + lane;
             int cnt = 0, start = 0, end = X.n - 1, depth = 0, prefix = 0;
             if (t < Q.npref) {
-                prefix = pm.prefix_of(t);
+                prefix = pm.prefix_of_fast(t);
                 // Hits with 1..4 sampled suffixes behind the 10-mer (all but a fraction of a percent on a non-repetitive
                 // reference) are evaluated directly.  The child-table descent reaches, by construction, the deepest match M of
                 // P[prefix..] among the suffixes of the interval and ends on the sub-interval of the suffixes that attain it (at a
@@ -1131,6 +1138,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
     SeedQ* hq = cx->h_tasks.as<SeedQ>();
     size_t po = PADB;
     memset(hp, 0, PADB);
+    bool magic_ok = true;       // every read short enough for the exact multiply-high prefix mapping (< 65536 prefixes)
     int64_t total_pref = 0, scr_ints = 0;
     int max_w = 0;
     for (int i = 0; i < nq; ++i) {
@@ -1149,6 +1157,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
             s.pm_nh = (int32_t)nh;
             s.pm_kh = (int32_t)std::min<int64_t>(kk, rr + 1);
             s.pm_m1 = s.pm_m2 = 0;
+            if (np >= 65536 || nh >= 65536) magic_ok = false;
             if (np < 65536 && nh >= 2 && nh < 65536) {
                 s.pm_m1 = (uint32_t)((0x100000000ull + (uint64_t)nh - 1) / (uint64_t)nh);
                 if (nh >= 3) s.pm_m2 = (uint32_t)((0x100000000ull + (uint64_t)(nh - 1) - 1) / (uint64_t)(nh - 1));
@@ -1171,7 +1180,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
         if (!pl->lds_tab && (rc = pl->d_scr.reserve(4 * (size_t)scr_ints + 64))) return rc;
     }
     static const bool force_simple = getenv("ALFA_SEED_SIMPLE") != nullptr;   // A/B switch for profiling
-    pl->persistent = mem_type == ALFA_SEED_SMAM && ix->has_child && ix->has_kmer && !force_simple;
+    pl->persistent = mem_type == ALFA_SEED_SMAM && ix->has_child && ix->has_kmer && !force_simple && magic_ok;
     pl->nseg = 1;
     if (pl->persistent) {
         static int n_cu[64] = {0};
