@@ -45,6 +45,12 @@ struct Ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // side streams: independent kernel chains of one batch (one per kernel bin) fork from `stream` and join it again,
+    // so that a bin holding a handful of long tasks does not serialise behind (or in front of) the others
+    static constexpr int NSIDE = 6;
+    hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t side_ev[NSIDE] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr;
     // staging
     DevBuf d_in, d_in2, d_tasks, d_out, d_out2, d_scratch, d_z, d_cnt, d_off, d_ivl;
     PinBuf h_in, h_in2, h_tasks, h_out, h_out2;

@@ -55,6 +55,9 @@ int Ctx::ensure(int dev) {
         device = dev;
         ALFA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (auto& e : ev) ALFA_HIP(hipEventCreate(&e));
+        for (auto& st : side) ALFA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (auto& e : side_ev) ALFA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ALFA_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
     }
     return ALFA_OK;
 }

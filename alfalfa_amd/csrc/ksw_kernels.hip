@@ -614,6 +614,48 @@ __global__ void ksw_backtrack_kernel(const DevTask* __restrict__ tasks, int ntas
     ncig[T.orig] = n;
 }
 
+// Same walk for small tasks (direction matrix of at most ZC bytes): every lane first copies its task's matrix into its own
+// LDS slice with independent 16-byte loads, then walks it there -- ~50 dependent LDS reads instead of ~50 dependent HBM reads.
+constexpr int ZC = 512;        // 64 tasks per workgroup
+constexpr int ZC2 = 2048;      // 16 tasks per workgroup
+template <int ZC, int TPB>
+__global__ __launch_bounds__(TPB) void ksw_backtrack_lds_kernel(const DevTask* __restrict__ tasks, int ntask, const uint8_t* __restrict__ zbuf,
+                                                               uint32_t* __restrict__ cig, int32_t* __restrict__ ncig, int ROWB) {
+    __shared__ uint4 zl[TPB * ZC / 16];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntask) return;
+    const DevTask T = tasks[t];
+    const int qlen = T.qlen, tlen = T.tlen, w = T.w;
+    const int nv = (tlen * ROWB + 15) >> 4;
+    const uint4* src = (const uint4*)(zbuf + T.zoff);
+    uint4* mine = zl + threadIdx.x * (ZC / 16);
+    for (int k = 0; k < nv; ++k) mine[k] = src[k];
+    const uint8_t* z = (const uint8_t*)mine;
+    uint32_t* slot = cig + T.cigoff;
+    int pos = T.cigcap;
+    int n = 0;
+    uint32_t cur_op = 0xffffffffu, cur_len = 0;
+    auto push = [&](uint32_t op, uint32_t len) {
+        if (op == cur_op) { cur_len += len; return; }
+        if (cur_op != 0xffffffffu) { slot[--pos] = cur_len << 4 | cur_op; ++n; }
+        cur_op = op; cur_len = len;
+    };
+    if (tlen > qlen + w) { ncig[T.orig] = -1; return; }   // reference indexes outside the matrix: unspecified
+    int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+    int which = 0;
+    while (i >= 0 && k >= 0) {
+        const uint32_t zv = z[i * ROWB + (k - i + w)];
+        which = (zv >> (which << 1)) & 3;
+        if (which == 0) { push(0, 1); --i; --k; }
+        else if (which == 1) { push(2, 1); --i; }
+        else { push(1, 1); --k; }
+    }
+    if (i >= 0) push(2, (uint32_t)(i + 1));
+    if (k >= 0) push(1, (uint32_t)(k + 1));
+    if (cur_op != 0xffffffffu) { slot[--pos] = cur_len << 4 | cur_op; ++n; }
+    ncig[T.orig] = n;
+}
+
 // ---------------------------------------------------------------- lane-per-task kernels
 // The reference loops (ksw.c:391-443, 491-522, 524-538) run literally, one task per lane.  Two storage policies:
 //   LDS=true   the throughput path for short tasks (the bulk of a short-read workload: queries of 20-100 residues):
@@ -795,6 +837,7 @@ struct alfa_dp_batch {
     std::vector<DevTask> ht;        // device order, .orig already remapped to the dense output index
     std::vector<int> dense_of;      // device order -> caller index
     int bin_cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // lane kernel (qlen <= 30, 62, 126), group kernel C=1,2,4, wave kernel C=2,4, generic
+    int nbig[3] = {0, 0, 0}, nbig2[3] = {0, 0, 0};   // group bins: tasks whose direction matrix exceeds ZC / ZC2 bytes (prefixes: sorted by tlen)
     int64_t cig_words = 0, cells = 0, zbytes = 0, eh_items = 0;
     size_t seq_bytes = 0, out_bytes = 0;
     alfa::DevBuf d_seq, d_tasks, d_out, d_z, d_cig, d_eh;
@@ -861,7 +904,8 @@ void launch_group(hipStream_t st, const DevTask* d_tasks, int n, const uint8_t* 
 }
 
 template <int MODE>
-void launch_all(alfa_dp_batch* b, hipStream_t st) {
+void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
+    hipStream_t st = cx->stream;
     const DevParams* d_prm = b->d_tasks.as<DevParams>();
     const DevTask* d_t = (const DevTask*)(d_prm + 1);
     const uint8_t* d_seq = b->d_seq.as<uint8_t>();
@@ -889,27 +933,52 @@ void launch_all(alfa_dp_batch* b, hipStream_t st) {
         o += bc[k];
     }
     // bands of up to 16 / 32 / 64 diagonals: 16 lanes per task
-    launch_group<MODE, 1>(st, d_t + o, bc[3], d_seq, d_prm, d_out, d_z);
-    if (MODE == MODE_GLOBAL && bc[3])
-        hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[3] + 63) / 64), dim3(64), 0, st, d_t + o, bc[3], d_z, d_cig, d_ncig, GL * 1);
-    o += bc[3];
-    launch_group<MODE, 2>(st, d_t + o, bc[4], d_seq, d_prm, d_out, d_z);
-    if (MODE == MODE_GLOBAL && bc[4])
-        hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[4] + 63) / 64), dim3(64), 0, st, d_t + o, bc[4], d_z, d_cig, d_ncig, GL * 2);
-    o += bc[4];
-    launch_group<MODE, 4>(st, d_t + o, bc[5], d_seq, d_prm, d_out, d_z);
-    if (MODE == MODE_GLOBAL && bc[5])
-        hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[5] + 63) / 64), dim3(64), 0, st, d_t + o, bc[5], d_z, d_cig, d_ncig, GL * 4);
-    o += bc[5];
+    // Every bin is an independent chain (fill kernel -> backtrack): the chains fork onto side streams and join again.
+    // Tasks of a bin are ordered by tlen, longest first: the first nbig2 direction matrices exceed ZC2 bytes (backtrack walks
+    // HBM), the next ones up to nbig exceed ZC (LDS slices of ZC2), the rest fit ZC.
+    (void)hipEventRecord(cx->fork_ev, st);
+    int used = 0;
+    auto side = [&](int n) -> hipStream_t {
+        if (n <= 0) return st;
+        hipStream_t s2 = cx->side[used % alfa::Ctx::NSIDE];
+        if (used < alfa::Ctx::NSIDE) (void)hipStreamWaitEvent(s2, cx->fork_ev, 0);
+        ++used;
+        return s2;
+    };
+    for (int g = 0; g < 3; ++g) {
+        const int n = bc[3 + g], nbig = b->nbig[g], nbig2 = b->nbig2[g], rowb = GL << g;
+        hipStream_t s2 = side(n);
+        if (g == 0) launch_group<MODE, 1>(s2, d_t + o, n, d_seq, d_prm, d_out, d_z);
+        else if (g == 1) launch_group<MODE, 2>(s2, d_t + o, n, d_seq, d_prm, d_out, d_z);
+        else launch_group<MODE, 4>(s2, d_t + o, n, d_seq, d_prm, d_out, d_z);
+        if (MODE == MODE_GLOBAL && nbig2 > 0)
+            hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((nbig2 + 63) / 64), dim3(64), 0, s2, d_t + o, nbig2, d_z, d_cig, d_ncig, rowb);
+        if (MODE == MODE_GLOBAL && nbig > nbig2)
+            hipLaunchKernelGGL((ksw_backtrack_lds_kernel<ZC2, 16>), dim3((nbig - nbig2 + 15) / 16), dim3(16), 0, s2, d_t + o + nbig2,
+                               nbig - nbig2, d_z, d_cig, d_ncig, rowb);
+        if (MODE == MODE_GLOBAL && n > nbig)
+            hipLaunchKernelGGL((ksw_backtrack_lds_kernel<ZC, 64>), dim3((n - nbig + 63) / 64), dim3(64), 0, s2, d_t + o + nbig, n - nbig, d_z,
+                               d_cig, d_ncig, rowb);
+        o += n;
+    }
     // bands of up to 128 / 256 diagonals: a whole wavefront per task
-    launch_wave<MODE, 2>(st, d_t + o, bc[6], d_seq, d_prm, d_out, d_z);
-    if (MODE == MODE_GLOBAL && bc[6])
-        hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[6] + 63) / 64), dim3(64), 0, st, d_t + o, bc[6], d_z, d_cig, d_ncig, 64 * 2);
-    o += bc[6];
-    launch_wave<MODE, 4>(st, d_t + o, bc[7], d_seq, d_prm, d_out, d_z);
-    if (MODE == MODE_GLOBAL && bc[7])
-        hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[7] + 63) / 64), dim3(64), 0, st, d_t + o, bc[7], d_z, d_cig, d_ncig, 64 * 4);
-    o += bc[7];
+    {
+        hipStream_t s2 = side(bc[6]);
+        launch_wave<MODE, 2>(s2, d_t + o, bc[6], d_seq, d_prm, d_out, d_z);
+        if (MODE == MODE_GLOBAL && bc[6])
+            hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[6] + 63) / 64), dim3(64), 0, s2, d_t + o, bc[6], d_z, d_cig, d_ncig, 64 * 2);
+        o += bc[6];
+        s2 = side(bc[7]);
+        launch_wave<MODE, 4>(s2, d_t + o, bc[7], d_seq, d_prm, d_out, d_z);
+        if (MODE == MODE_GLOBAL && bc[7])
+            hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[7] + 63) / 64), dim3(64), 0, s2, d_t + o, bc[7], d_z, d_cig, d_ncig, 64 * 4);
+        o += bc[7];
+    }
+    const int nside = used < alfa::Ctx::NSIDE ? used : alfa::Ctx::NSIDE;
+    for (int k = 0; k < nside; ++k) {
+        (void)hipEventRecord(cx->side_ev[k], cx->side[k]);
+        (void)hipStreamWaitEvent(st, cx->side_ev[k], 0);
+    }
     if (bc[8])
         hipLaunchKernelGGL((ksw_lane_kernel<MODE, false>), dim3((bc[8] + 63) / 64), dim3(64), 0, st, d_t + o, bc[8], d_seq, d_prm, d_out,
                            b->d_eh.as<int2>(), d_z, d_cig, d_ncig, 0);
@@ -922,6 +991,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
     b->mode = mode; b->n = n; b->device = cx->device; b->launched = false; b->kernel_ms = 0;
     b->cig_words = b->cells = b->zbytes = b->eh_items = 0;
     for (int k = 0; k < 9; ++k) b->bin_cnt[k] = 0;
+    for (int k = 0; k < 3; ++k) b->nbig[k] = b->nbig2[k] = 0;
     b->ht.resize((size_t)n);
     b->dense_of.resize((size_t)n);
     if (!b->ev0) { ALFA_HIP(hipEventCreate(&b->ev0)); ALFA_HIP(hipEventCreate(&b->ev1)); }
@@ -943,6 +1013,8 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         else { const int W = 2 * w_eff[i] + 1; bin = W <= 16 ? 3 : W <= 32 ? 4 : W <= 64 ? 5 : W <= 128 ? 6 : W <= 256 ? 7 : 8; }
         bins[i] = bin;
         b->bin_cnt[bin]++;
+        if (bin >= 3 && bin <= 5 && (int64_t)x.tlen * (GL << (bin - 3)) > ZC) b->nbig[bin - 3]++;
+        if (bin >= 3 && bin <= 5 && (int64_t)x.tlen * (GL << (bin - 3)) > ZC2) b->nbig2[bin - 3]++;
         seq_bytes += (size_t)x.qlen + (size_t)x.tlen;
     }
     // order: by bin; inside a bin the most work first, so that the 64 tasks of a lane-kernel wave (and co-resident waves of the
@@ -1037,9 +1109,9 @@ int launch_batch(alfa_dp_batch* b, Ctx* cx) {
     if (b->n == 0) { b->launched = true; return ALFA_OK; }
     hipStream_t st = cx->stream;
     ALFA_HIP(hipEventRecord(b->ev0, st));
-    if (b->mode == MODE_EXTEND) launch_all<MODE_EXTEND>(b, st);
-    else if (b->mode == MODE_NW) launch_all<MODE_NW>(b, st);
-    else launch_all<MODE_GLOBAL>(b, st);
+    if (b->mode == MODE_EXTEND) launch_all<MODE_EXTEND>(b, cx);
+    else if (b->mode == MODE_NW) launch_all<MODE_NW>(b, cx);
+    else launch_all<MODE_GLOBAL>(b, cx);
     ALFA_HIP(hipGetLastError());
     ALFA_HIP(hipEventRecord(b->ev1, st));
     b->launched = true;
