@@ -151,6 +151,14 @@ Read::Read(Read&& o) noexcept
     o.alignments.clear();
 }
 
+void Read::release() {
+    for (Alignment* a : alignments) delete a;
+    std::vector<Alignment*>().swap(alignments);
+    std::string().swap(sequence); std::string().swap(rcSequence); std::string().swap(qual); std::string().swap(rQual);
+    std::string().swap(qname);
+    std::vector<uint8_t>().swap(readP); std::vector<uint8_t>().swap(rcReadP);
+}
+
 void Read::init() {
     rcSequence = sequence;
     std::reverse(rcSequence.begin(), rcSequence.end());

@@ -367,6 +367,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                         c[1] += k;
                         for (int j = 0; j < k; j++) txt += r.printUnpaired(j);
                     }
+                    r.release();          // on the worker: the writer thread only writes
                 }
             });
         printf("sequences read: %ld\nsequences mapped: %ld\nalignments printed: %ld\n", total, mapped1, printed1);
@@ -414,6 +415,8 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                         c[3] += k;
                         for (int j = 0; j < k; j++) txt += m2.printPaired(j, false);
                     }
+                    m1.release();
+                    m2.release();
                 }
             });
         printf("sequences read: %ld\nsequences mapped (mate1): %ld\nsequences mapped (mate2): %ld\n"
