@@ -153,10 +153,8 @@ Read::Read(Read&& o) noexcept
 
 void Read::release() {
     for (Alignment* a : alignments) delete a;
-    std::vector<Alignment*>().swap(alignments);
-    std::string().swap(sequence); std::string().swap(rcSequence); std::string().swap(qual); std::string().swap(rQual);
-    std::string().swap(qname);
-    std::vector<uint8_t>().swap(readP); std::vector<uint8_t>().swap(rcReadP);
+    alignments.clear();
+    pairedAlignmentCount = 0;
 }
 
 void Read::init() {

@@ -82,7 +82,8 @@ struct Read {                     // read_t src/mapper.h:126-219
     Read& operator=(const Read&) = delete;
     Read(Read&& o) noexcept;
     void init();                  // read_t::init src/mapper.h:155-166
-    void release();               // frees everything once the read's SAM lines are rendered
+    void release();               // drops the alignments once the read's SAM lines are rendered (strings keep their capacity:
+                                  // the object is reused for a later read of the input)
     std::string emptyAlignment(bool paired, bool mateFailed, bool upstream) const;
     std::string printUnpaired(int i) const;
     std::string printPaired(int i, bool firstMate);

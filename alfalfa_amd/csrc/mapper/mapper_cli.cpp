@@ -136,12 +136,13 @@ bool parse(int argc, char** argv, Options& o) {
 
 // fastqInputReader::nextRead src/fasta.cpp:135-159 + the '/1' '/2' stripping of src/main.cpp:91-92
 bool next_read(SeqReader& rd, Read& r) {
-    SeqRecord rec;
+    static thread_local SeqRecord rec;       // buffers reused from record to record
     if (rd.next(rec) < 0) return false;
     r.qname = rec.name;
     r.sequence = rec.seq;
     for (auto& c : r.sequence) c = (char)std::tolower((unsigned char)c);
     if (!rec.qual.empty()) r.qual = rec.qual;
+    else r.qual = "*";
     if (r.qname.length() > 2 && r.qname[r.qname.length() - 2] == '/') r.qname.erase(r.qname.length() - 2);
     return true;
 }
@@ -199,6 +200,14 @@ class Chan {
         cv_.wait(g, [&] { return q_.size() < cap_; });
         q_.push_back(std::move(v));
         cv_.notify_all();
+    }
+    bool try_pop(T& v) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (q_.empty()) return false;
+        v = std::move(q_.front());
+        q_.pop_front();
+        cv_.notify_all();
+        return true;
     }
     bool pop(T& v) {
         std::unique_lock<std::mutex> g(mu_);
@@ -287,7 +296,8 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     const size_t readCap = (size_t)T * (size_t)std::max(256, o.fibers);
 
     struct Batch {
-        std::vector<Read> a, b;               // b stays empty for single-end input
+        std::vector<Read> a, b;               // b stays empty for single-end input; objects beyond n are spares of earlier batches
+        int n = 0;                            // reads (pairs) of this batch
         std::vector<std::string> text;        // rendered SAM, one chunk per worker slice, in input order
         std::vector<long> cnt;                // per slice: mapped1, printed1, mapped2, printed2
     };
@@ -298,11 +308,14 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
 
     // fill(batch) -> false at end of input; work(batch, t, lo, hi) maps and renders reads [lo,hi) on worker t
     auto stream = [&](const std::function<bool(Batch&)>& fill, const std::function<void(Batch&, int, int, int)>& work) {
-        Chan<BatchP> parsed(2), mapped(2);
+        // batches circulate reader -> mapping -> writer -> reader, so that the reads' strings are allocated once
+        Chan<BatchP> parsed(2), mapped(2), spare(8);
         std::thread reader([&] {
             for (;;) {
                 double t0 = now();
-                BatchP bp(new Batch);
+                BatchP bp;
+                if (!spare.try_pop(bp)) bp.reset(new Batch);
+                bp->n = 0;
                 bool ok = fill(*bp);
                 t_parse += now() - t0;
                 if (!ok) break;
@@ -315,7 +328,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
             while (mapped.pop(bp)) {
                 double t0 = now();
                 for (const std::string& s : bp->text) fwrite(s.data(), 1, s.size(), out);
-                bp.reset();                    // frees the reads and their alignments off the mapping threads
+                spare.push(std::move(bp));
                 t_print += now() - t0;
             }
         });
@@ -323,7 +336,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         while (parsed.pop(bp)) {
             double t0 = now();
             Batch& B = *bp;
-            const int n = (int)B.a.size();
+            const int n = B.n;
             total += n;
             B.text.assign((size_t)T, std::string());
             B.cnt.assign((size_t)T * 4, 0);
@@ -345,13 +358,14 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         stream(
             [&](Batch& B) {
                 int64_t cur = 0;
-                while (cur < bpCount && B.a.size() < readCap) {
-                    Read r;
+                while (cur < bpCount && (size_t)B.n < readCap) {
+                    if ((int)B.a.size() <= B.n) B.a.emplace_back();
+                    Read& r = B.a[B.n];
                     if (!next_read(rd, r)) break;
                     cur += (int64_t)r.sequence.length();
-                    B.a.push_back(std::move(r));
+                    B.n++;
                 }
-                return !B.a.empty();
+                return B.n > 0;
             },
             [&](Batch& B, int t, int lo, int hi) {
                 Mapper& mp = *mappers[t];
@@ -379,17 +393,18 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         stream(
             [&](Batch& B) {
                 int64_t cur = 0;
-                while (cur < bpCount && B.a.size() < readCap) {
-                    Read a, b;
+                while (cur < bpCount && (size_t)B.n < readCap) {
+                    if ((int)B.a.size() <= B.n) { B.a.emplace_back(); B.b.emplace_back(); }
+                    Read& a = B.a[B.n];
+                    Read& b = B.b[B.n];
                     bool ok1 = next_read(r1, a);
                     bool ok2 = next_read(r2, b);     // the reference keeps only the second status (src/main.cpp:157-158)
                     (void)ok1;
                     if (!ok2) break;
                     cur += (int64_t)a.sequence.length();
-                    B.a.push_back(std::move(a));
-                    B.b.push_back(std::move(b));
+                    B.n++;
                 }
-                return !B.a.empty();
+                return B.n > 0;
             },
             [&](Batch& B, int t, int lo, int hi) {
                 Mapper& mp = *mappers[t];
