@@ -168,7 +168,7 @@ def main():
     ap.add_argument("--sparseness", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20000)
-    ap.add_argument("--e2e-reads", type=int, default=300000, help="reads for the end-to-end command line comparison (0 = skip)")
+    ap.add_argument("--e2e-reads", type=int, default=1000000, help="reads for the end-to-end command line comparison (0 = skip)")
     ap.add_argument("--e2e-threads", type=int, default=16)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for --dist-selftest)")
     ap.add_argument("--dist-selftest", action="store_true", help="CPU rehearsal of the multi-rank control flow, no GPU work")
@@ -389,6 +389,10 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_note": "raw FETCH_SIZE x 1024 per dispatch (profiles/r01_pmc_traffic.json). Calibrated on this access pattern "
+                            "(tools/fetch_calib.hip, profiles/r01_fetch_calibration.csv): an isolated 4/8/16-byte gather from a 2 GiB "
+                            "table tallies 64 B, a wide streaming read tallies half its bytes (the guide's x2 case); the seed "
+                            "kernels issue gathers, so the raw figure is used",
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "algorithmic_bytes_per_read": bytes_per_read,
             "avg_launch_ms": seed_avg_ms,
