@@ -489,6 +489,7 @@ __device__ __forceinline__ int wave_alloc_slot(int* counter, bool want) {
 constexpr int PBLOCK = 1024;
 constexpr int PWAVES = PBLOCK / 64;
 constexpr int KBIT_BYTES = (int)(TABLE / 8);
+constexpr int WQ_BYTES = 128 * 8;                // per-wave queue of bitmap survivors {prefix, 10-mer code}
 
 __device__ __forceinline__ int wave_excl_scan(int v, int& total) {
     const int lane = threadIdx.x & 63;
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
     __syncthreads();
     work += (size_t)blockIdx.x * seg_cap;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint8_t* mybuf = smem + KBIT_BYTES + (size_t)wid * 2 * lds_stride;
+    uint8_t* mybuf = smem + KBIT_BYTES + (size_t)wid * (2 * lds_stride + WQ_BYTES);
     const int K = X.K;
     for (int r = blockIdx.x * PWAVES + wid; r < nq; r += gridDim.x * PWAVES) {      // wave-uniform
         const SeedQ Q = qs[r];
@@ -549,11 +550,44 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
         const int maxCount = Q.sparse_q * Q.max_count;
         const bool use_kmer = Q.plen >= KMER;                   // traverse_faster is called with min_len = |P| (:1073)
         int running = 0;
-        for (int base = 0; base < Q.npref; base += 64) {
-            const int t = base + lane;
-            int cnt = 0, start = 0, end = X.n - 1, depth = 0, prefix = 0;
-            if (t < Q.npref) {
-                prefix = pm.prefix_of_fast(t);
+        // Two thirds of the queries die at the presence bitmap.  A cheap filter stage (prefix, 10-mer code, bit test) runs over
+        // the queries 64 at a time and appends the survivors, in query order, to the wave's queue in LDS; the expensive stage
+        // (table entry, text comparisons, left extension, scan, work record) then runs on 64 survivors at a time -- all lanes
+        // busy -- instead of on every chunk of 64 queries with a third of its lanes alive.
+        uint2* wq = (uint2*)(mybuf + 2 * lds_stride);           // {prefix, 10-mer code}, capacity 128
+        int qn = 0, base = 0;
+        for (;;) {
+            while (qn < 64 && base < Q.npref) {
+                const int t = base + lane;
+                bool keep = t < Q.npref;
+                int pf = 0;
+                uint32_t index = 0xFFFFFFFFu;
+                if (keep) {
+                    pf = pm.prefix_of_fast(t);
+                    if (use_kmer) {
+                        index = !in_lds ? kmer_code(P, pf) : (pf + KMER <= Q.plen ? kmer_code_packed(codes, pf) : 0xFFFFFFFFu);
+                        keep = index < TABLE && ((bits[index >> 5] >> (index & 31)) & 1u);
+                    }
+                }
+                const uint64_t m = __ballot(keep);
+                if (keep) wq[qn + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)pf, index);
+                qn += __popcll(m);
+                base += 64;
+            }
+            if (qn == 0) break;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int take = qn < 64 ? qn : 64;
+            const bool have = lane < take;
+            const uint2 ent = have ? wq[lane] : make_uint2(0u, 0xFFFFFFFFu);
+            const uint2 mv = (lane + 64 < qn) ? wq[lane + 64] : make_uint2(0u, 0u);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane + 64 < qn) wq[lane] = mv;                  // the rest of the queue moves to the front
+            qn -= take;
+            int cnt = 0, start = 0, end = X.n - 1, depth = 0, prefix = (int)ent.x;
+            if (have) {
                 // Hits with 1..4 sampled suffixes behind the 10-mer (all but a fraction of a percent on a non-repetitive
                 // reference) are evaluated directly.  The child-table descent reaches, by construction, the deepest match M of
                 // P[prefix..] among the suffixes of the interval and ends on the sub-interval of the suffixes that attain it (at a
@@ -568,9 +602,8 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
                 int off0 = 0;
                 const int c0 = prefix + KMER;
                 if (use_kmer) {
-                    const uint32_t index = !in_lds ? kmer_code(P, prefix) : (prefix + KMER <= Q.plen ? kmer_code_packed(codes, prefix) : 0xFFFFFFFFu);
-                    alive = index < TABLE && ((bits[index >> 5] >> (index & 31)) & 1u);
-                    if (alive) {
+                    const uint32_t index = ent.y;               // passed the bitmap in the filter stage
+                    {
                         const uint4 e = X.KMR2[index];
                         depth = KMER; start = (int)e.x; end = (int)e.y;
                         const int nsuf = end - start + 1;
@@ -1192,7 +1225,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
             ncu = std::max(1, prop.multiProcessorCount);
         }
         pl->nseg = std::max(1, std::min(ncu, (nq + PWAVES - 1) / PWAVES));
-        const int room = (160 * 1024 - KBIT_BYTES - 1024) / PWAVES / 2;                   // LDS bytes a wave can have for its read (x2: codes)
+        const int room = ((160 * 1024 - KBIT_BYTES - 1024) / PWAVES - WQ_BYTES) / 2;      // LDS bytes a wave can have for its read (x2: codes)
         pl->stride = std::min(room & ~15, (max_plen + 2 * PADB + 15) & ~15);              // longer reads are read from global memory
     }
     const int64_t total_cap = std::min<int64_t>(std::max<int64_t>(4096, 4 * (int64_t)nq), std::max<int64_t>(total_pref, 1));
@@ -1227,7 +1260,7 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
     ALFA_HIP(hipEventRecord(pl->ev0, st));
     if (pl->persistent) {
         // one workgroup per CU, the 10-mer bitmap + one read slice per wave in LDS
-        const size_t lds = (size_t)KBIT_BYTES + (size_t)PWAVES * 2 * pl->stride;      // read bytes + 2-bit codes per wave
+        const size_t lds = (size_t)KBIT_BYTES + (size_t)PWAVES * (2 * pl->stride + WQ_BYTES);      // read bytes + 2-bit codes + survivor queue per wave
         hipLaunchKernelGGL(smam_count_kernel, dim3(pl->nseg), dim3(PBLOCK), lds, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec>(), d_cnt,
                            pl->seg_cap, nq, pl->stride);
     } else if (pl->mem_type == ALFA_SEED_SMAM) {
