@@ -503,9 +503,14 @@ __device__ __forceinline__ int wave_excl_scan(int v, int& total) {
     return inc - v;
 }
 
+// A survivor of the table stage that may still emit matches: everything the evaluation stage needs.
+struct Q3 { int32_t read, prefix, start, end; uint32_t z, w; };     // prefix bit 31: query without 10-mer jump (|P| < 10)
+constexpr int Q3_CAP = 128;
+
 __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
-                                                           int64_t* __restrict__ read_total, WorkRec* __restrict__ work,
-                                                           int* __restrict__ seg_count, int seg_cap, int nq, int lds_stride) {
+                                                           unsigned long long* __restrict__ read_total, WorkRec* __restrict__ work,
+                                                           int* __restrict__ seg_count, int seg_cap, int nq, int lds_stride,
+                                                           Q3* __restrict__ q3_all) {
     extern __shared__ uint8_t smem[];
     __shared__ int sh_wcount;                                   // records in this workgroup's segment of the work list
     uint32_t* bits = (uint32_t*)smem;
@@ -516,6 +521,141 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint8_t* mybuf = smem + KBIT_BYTES + (size_t)wid * (2 * lds_stride + WQ_BYTES);
     const int K = X.K;
+    // Three stages with a queue between each pair; a stage only runs when its input queue holds a full wave of work:
+    //   1 filter    prefix, 10-mer code, presence bit (LDS only)                       queries  -> wq (LDS, this read)
+    //   2 table     KMR2 entry; single-suffix hits that mismatch within the entry's 4 text bytes and cannot reach min_lenK
+    //               are finished here (9 in 10 survivors)                             wq       -> q3 (HBM, across reads)
+    //   3 evaluate  text comparisons / child-table descent, left extension, offsets   q3       -> work list
+    // Queue order is (read, query) order, and only stage 3 emits, so offsets inside a read stay in the reference's order.
+    Q3* q3 = q3_all + (size_t)(blockIdx.x * PWAVES + wid) * Q3_CAP;
+    int q3n = 0;
+    int carry_r = -1, carry_run = 0;                             // offset reached inside the last read stage 3 has seen
+
+    auto evaluate = [&](int take) {
+        // this wave's q3 stores are visible to its own loads: one CU, one vector L1 -- a workgroup-scope fence (a wait for
+        // the stores) is enough; an agent-scope fence would write back / invalidate the XCD's L2 and costs 5x the kernel
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const bool have = lane < take;
+        Q3 ent;
+        ent.read = -1; ent.prefix = 0; ent.start = 0; ent.end = 0; ent.z = 0; ent.w = 0;
+        if (have) ent = q3[lane];
+        Q3 mv = ent;
+        const bool moves = lane + take < q3n;
+        if (moves) mv = q3[lane + take];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (moves) q3[lane] = mv;                               // the rest of the queue moves to the front
+        q3n -= take;
+        int cnt = 0, start = ent.start, end = ent.end, depth = 0;
+        const int prefix = ent.prefix & 0x7fffffff;
+        if (have) {
+            const SeedQ Q = qs[ent.read];
+            PatD P;
+            P.len = Q.plen;
+            P.p = reads + Q.poff;                               // the read's LDS copy may be gone: global bytes
+            const int step = Q.sparse_q * K;
+            const int min_lenK = Q.min_len - (step - 1);
+            const int minMin_len = Q.sparse_q > 1 ? Q.min_len - K : Q.min_len;
+            const int maxCount = Q.sparse_q * Q.max_count;
+            // Hits with 1..4 sampled suffixes behind the 10-mer (all but a fraction of a percent on a non-repetitive
+            // reference) are evaluated directly.  The child-table descent reaches, by construction, the deepest match M of
+            // P[prefix..] among the suffixes of the interval and ends on the sub-interval of the suffixes that attain it (at a
+            // branching node when no child continues P, inside an edge on a mismatch, or at the end of the read or text):
+            // with so few suffixes, M follows from comparing each of them with the read, all text chunks being independent
+            // loads (16 bytes per suffix and round trip) instead of ~10 dependent CHILD/LCP/SA/S probes.  A single suffix
+            // is the run of comparisons of :758,:781-786.
+            int64_t sas[4] = {0, 0, 0, 0};
+            int lim[4] = {-1, -1, -1, -1}, mi[4] = {-1, -1, -1, -1};     // -1: unused slot
+            bool go[4] = {false, false, false, false};
+            bool direct = false;
+            const int c0 = prefix + KMER;
+            if (ent.prefix >= 0) {
+                depth = KMER;
+                const int nsuf = end - start + 1;
+                if (nsuf >= 1 && nsuf <= 4) {
+                    direct = true;
+                    sas[0] = (int64_t)ent.z;
+                    if (nsuf >= 2) sas[1] = (int64_t)ent.w;
+                    if (nsuf >= 3) sas[2] = (int64_t)X.SA[start + 2];
+                    if (nsuf >= 4) sas[3] = (int64_t)X.SA[start + 3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < nsuf) {
+                            lim[k] = (int)max((int64_t)0, min((int64_t)(Q.plen - c0), X.N - (sas[k] + KMER)));
+                            mi[k] = 0;
+                            go[k] = lim[k] > 0;
+                        }
+                }
+            }
+            if (direct) {
+                for (int off = 0; go[0] || go[1] || go[2] || go[3]; off += 16) {
+                    uint64_t a0[4], a1[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (go[k]) { a0[k] = ld8(X.S + sas[k] + KMER + off); a1[k] = ld8(X.S + sas[k] + KMER + off + 8); }
+                    const uint64_t b0 = P.load8(c0 + off), b1 = P.load8(c0 + off + 8);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (go[k]) {
+                            const uint64_t x0 = a0[k] ^ b0, x1 = a1[k] ^ b1;
+                            int m = 16;
+                            if (x0) m = __builtin_ctzll(x0) >> 3;
+                            else if (x1) m = 8 + (__builtin_ctzll(x1) >> 3);
+                            if (!(m >= 16 && lim[k] > off + 16)) { mi[k] = min(off + m, lim[k]); go[k] = false; }
+                        }
+                }
+                const int M = max(max(mi[0], mi[1]), max(mi[2], mi[3]));
+                int ns = 3, ne = 0;
+#pragma unroll
+                for (int k = 3; k >= 0; --k) if (mi[k] == M) ns = k;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (mi[k] == M) ne = k;
+                depth = KMER + M;
+                end = start + ne; start = start + ns;
+                // keep the SA values of the surviving suffixes addressable by (rank - start)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) if (ns > k) { sas[0] = sas[1]; sas[1] = sas[2]; sas[2] = sas[3]; }
+            } else {
+                traverse_from(X, P, prefix, start, end, depth, Q.plen, -1);
+            }
+            if (depth > 1 && depth >= min_lenK && (end - start + 1) <= maxCount) {
+                int64_t mr; int mq, ml;
+                if (direct) {
+                    for (int k = 0; k <= end - start; ++k) {
+                        const int64_t sk = k == 0 ? sas[0] : k == 1 ? sas[1] : k == 2 ? sas[2] : sas[3];
+                        cnt += lmax_strict(X, P, prefix, sk, depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
+                    }
+                } else
+                    for (int i = start; i <= end; ++i)
+                        cnt += lmax_strict(X, P, prefix, (int64_t)X.SA[i], depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
+            }
+        }
+        // offsets: an exclusive scan over the wave, made relative to the first entry of the same read, plus what earlier
+        // evaluations already handed out inside that read
+        int total;
+        const int excl = wave_excl_scan(cnt, total);
+        const int r_prev = __shfl_up(ent.read, 1, 64);
+        const bool head = lane == 0 || r_prev != ent.read;
+        int hl = head ? lane : -1;                              // lane of the head of my run: inclusive max-scan
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(hl, off, 64); if (lane >= off) hl = max(hl, o); }
+        const int seg_base = __shfl(excl, hl, 64);
+        const int carried = ent.read == carry_r ? carry_run : 0;
+        const int woff = excl - seg_base + carried;
+        const int r_next = __shfl_down(ent.read, 1, 64);
+        const bool tail = have && (lane == take - 1 || r_next != ent.read);
+        const int run_total = excl + cnt - seg_base;
+        if (tail && run_total > 0) atomicAdd(&read_total[ent.read], (unsigned long long)run_total);
+        const int last_r = __shfl(ent.read, take - 1, 64);
+        const int last_total = __shfl(run_total + carried, take - 1, 64);
+        carry_r = last_r; carry_run = last_total;
+        const int slot = wave_alloc_slot(&sh_wcount, cnt > 0);
+        if (cnt > 0 && slot < seg_cap) {
+            WorkRec w;
+            w.read = ent.read; w.woff = woff; w.start = start; w.end = end; w.depth = depth; w.prefix = prefix;
+            work[slot] = w;
+        }
+    };
+
     for (int r = blockIdx.x * PWAVES + wid; r < nq; r += gridDim.x * PWAVES) {      // wave-uniform
         const SeedQ Q = qs[r];
         PatD P;
@@ -542,21 +682,15 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
         }
         const int step = Q.sparse_q * K;
         const int min_lenK = Q.min_len - (step - 1);
-        const int minMin_len = Q.sparse_q > 1 ? Q.min_len - K : Q.min_len;
         PrefixMap pm;
         pm.step = step;
         pm.Lmax = Q.plen - min_lenK;
         pm.nh = Q.pm_nh; pm.kh = Q.pm_kh; pm.m1 = Q.pm_m1; pm.m2 = Q.pm_m2;
-        const int maxCount = Q.sparse_q * Q.max_count;
         const bool use_kmer = Q.plen >= KMER;                   // traverse_faster is called with min_len = |P| (:1073)
-        int running = 0;
-        // Two thirds of the queries die at the presence bitmap.  A cheap filter stage (prefix, 10-mer code, bit test) runs over
-        // the queries 64 at a time and appends the survivors, in query order, to the wave's queue in LDS; the expensive stage
-        // (table entry, text comparisons, left extension, scan, work record) then runs on 64 survivors at a time -- all lanes
-        // busy -- instead of on every chunk of 64 queries with a third of its lanes alive.
         uint2* wq = (uint2*)(mybuf + 2 * lds_stride);           // {prefix, 10-mer code}, capacity 128
         int qn = 0, base = 0;
         for (;;) {
+            // ---- stage 1
             while (qn < 64 && base < Q.npref) {
                 const int t = base + lane;
                 bool keep = t < Q.npref;
@@ -586,107 +720,40 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
             __builtin_amdgcn_wave_barrier();
             if (lane + 64 < qn) wq[lane] = mv;                  // the rest of the queue moves to the front
             qn -= take;
-            int cnt = 0, start = 0, end = X.n - 1, depth = 0, prefix = (int)ent.x;
+            // ---- stage 2
+            bool defer = false;
+            Q3 out;
+            out.read = r; out.prefix = (int)ent.x; out.start = 0; out.end = X.n - 1; out.z = 0; out.w = 0;
             if (have) {
-                // Hits with 1..4 sampled suffixes behind the 10-mer (all but a fraction of a percent on a non-repetitive
-                // reference) are evaluated directly.  The child-table descent reaches, by construction, the deepest match M of
-                // P[prefix..] among the suffixes of the interval and ends on the sub-interval of the suffixes that attain it (at a
-                // branching node when no child continues P, inside an edge on a mismatch, or at the end of the read or text):
-                // with so few suffixes, M follows from comparing each of them with the read, all text chunks being independent
-                // loads (16 bytes per suffix and round trip) instead of ~10 dependent CHILD/LCP/SA/S probes.  A single suffix
-                // is the run of comparisons of :758,:781-786; its first 4 characters come with the table entry.
-                int64_t sas[4] = {0, 0, 0, 0};
-                int lim[4] = {-1, -1, -1, -1}, mi[4] = {-1, -1, -1, -1};     // -1: unused slot
-                bool go[4] = {false, false, false, false};
-                bool alive = true, direct = false;
-                int off0 = 0;
-                const int c0 = prefix + KMER;
-                if (use_kmer) {
-                    const uint32_t index = ent.y;               // passed the bitmap in the filter stage
-                    {
-                        const uint4 e = X.KMR2[index];
-                        depth = KMER; start = (int)e.x; end = (int)e.y;
-                        const int nsuf = end - start + 1;
-                        if (nsuf >= 1 && nsuf <= 4) {
-                            direct = true;
-                            sas[0] = (int64_t)e.z;
-                            if (nsuf >= 2) sas[1] = (int64_t)e.w;
-                            if (nsuf >= 3) sas[2] = (int64_t)X.SA[start + 2];
-                            if (nsuf >= 4) sas[3] = (int64_t)X.SA[start + 3];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                if (k < nsuf) {
-                                    lim[k] = (int)max((int64_t)0, min((int64_t)(Q.plen - c0), X.N - (sas[k] + KMER)));
-                                    mi[k] = 0;
-                                    go[k] = lim[k] > 0;
-                                }
-                            if (nsuf == 1 && go[0]) {
-                                const uint32_t x = e.w ^ (uint32_t)P.load8(c0);
-                                const int m4 = x ? (__builtin_ctz(x) >> 3) : 4;
-                                if (m4 < 4 || lim[0] <= 4) { mi[0] = min(m4, lim[0]); go[0] = false; }
-                                else off0 = 4;
-                            }
+                if (!use_kmer) { defer = true; out.prefix |= (int)0x80000000; }
+                else {
+                    const uint4 e = X.KMR2[ent.y];
+                    out.start = (int)e.x; out.end = (int)e.y; out.z = e.z; out.w = e.w;
+                    defer = true;
+                    if (e.x == e.y) {
+                        // single suffix: its first 4 characters come with the entry; most random hits end here
+                        const int c0 = (int)ent.x + KMER;
+                        const int lim0 = (int)max((int64_t)0, min((int64_t)(Q.plen - c0), X.N - ((int64_t)e.z + KMER)));
+                        int d = KMER;
+                        bool resolved = lim0 <= 0;
+                        if (lim0 > 0) {
+                            const uint32_t x = e.w ^ (uint32_t)P.load8(c0);
+                            const int m4 = x ? (__builtin_ctz(x) >> 3) : 4;
+                            if (m4 < 4 || lim0 <= 4) { d += min(m4, lim0); resolved = true; }
                         }
+                        if (resolved && !(d > 1 && d >= min_lenK)) defer = false;      // finished, and too short to emit
                     }
                 }
-                if (direct) {
-                    for (int off = off0; go[0] || go[1] || go[2] || go[3]; off += 16) {
-                        uint64_t a0[4], a1[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (go[k]) { a0[k] = ld8(X.S + sas[k] + KMER + off); a1[k] = ld8(X.S + sas[k] + KMER + off + 8); }
-                        const uint64_t b0 = P.load8(c0 + off), b1 = P.load8(c0 + off + 8);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (go[k]) {
-                                const uint64_t x0 = a0[k] ^ b0, x1 = a1[k] ^ b1;
-                                int m = 16;
-                                if (x0) m = __builtin_ctzll(x0) >> 3;
-                                else if (x1) m = 8 + (__builtin_ctzll(x1) >> 3);
-                                if (!(m >= 16 && lim[k] > off + 16)) { mi[k] = min(off + m, lim[k]); go[k] = false; }
-                            }
-                    }
-                    const int M = max(max(mi[0], mi[1]), max(mi[2], mi[3]));
-                    int ns = 3, ne = 0;
-#pragma unroll
-                    for (int k = 3; k >= 0; --k) if (mi[k] == M) ns = k;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) if (mi[k] == M) ne = k;
-                    depth = KMER + M;
-                    end = start + ne; start = start + ns;
-                    // keep the SA values of the surviving suffixes addressable by (rank - start)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) if (ns > k) { sas[0] = sas[1]; sas[1] = sas[2]; sas[2] = sas[3]; }
-                } else if (alive) {
-                    traverse_from(X, P, prefix, start, end, depth, Q.plen, -1);
-                }
-                if (alive && depth > 1 && depth >= min_lenK && (end - start + 1) <= maxCount) {
-                    int64_t mr; int mq, ml;
-                    if (direct) {
-                        for (int k = 0; k <= end - start; ++k) {
-                            const int64_t sk = k == 0 ? sas[0] : k == 1 ? sas[1] : k == 2 ? sas[2] : sas[3];
-                            cnt += lmax_strict(X, P, prefix, sk, depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
-                        }
-                    } else
-                        for (int i = start; i <= end; ++i)
-                            cnt += lmax_strict(X, P, prefix, (int64_t)X.SA[i], depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
-                }
             }
-            int total;
-            const int excl = wave_excl_scan(cnt, total);
-            const int slot = wave_alloc_slot(&sh_wcount, cnt > 0);
-            if (cnt > 0) {
-                if (slot < seg_cap) {
-                    WorkRec w;
-                    w.read = r; w.woff = running + excl; w.start = start; w.end = end; w.depth = depth; w.prefix = prefix;
-                    work[slot] = w;
-                }
-            }
-            running += total;
+            const uint64_t dm = __ballot(defer);
+            if (defer) q3[q3n + __popcll(dm & ((1ull << lane) - 1ull))] = out;
+            q3n += __popcll(dm);
+            // ---- stage 3 whenever a full wave of work is waiting
+            if (q3n >= 64) evaluate(64);
         }
-        if (lane == 0) read_total[r] = running;
         __builtin_amdgcn_wave_barrier();                        // the LDS slice is rewritten for the next read
     }
+    while (q3n > 0) evaluate(q3n < 64 ? q3n : 64);
     __syncthreads();
     if (threadIdx.x == 0) seg_count[blockIdx.x] = sh_wcount;
 }
@@ -1121,7 +1188,7 @@ struct alfa_seed_plan {
     bool persistent = false;
     int stride = 0;              // persistent kernel: LDS bytes per wave for its read
     int64_t out_cap = 0;
-    alfa::DevBuf d_reads, d_q, d_tot, d_base, d_work, d_cnt, d_out, d_tmp, d_scr;
+    alfa::DevBuf d_reads, d_q, d_tot, d_base, d_work, d_cnt, d_out, d_tmp, d_scr, d_q3;
     size_t tmp_bytes = 0;
     int mem_type = ALFA_SEED_SMAM;
     size_t work_rec = sizeof(WorkRec);
@@ -1227,6 +1294,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
         pl->nseg = std::max(1, std::min(ncu, (nq + PWAVES - 1) / PWAVES));
         const int room = ((160 * 1024 - KBIT_BYTES - 1024) / PWAVES - WQ_BYTES) / 2;      // LDS bytes a wave can have for its read (x2: codes)
         pl->stride = std::min(room & ~15, (max_plen + 2 * PADB + 15) & ~15);              // longer reads are read from global memory
+        if ((rc = pl->d_q3.reserve(sizeof(Q3) * (size_t)pl->nseg * PWAVES * Q3_CAP + 64))) return rc;
     }
     const int64_t total_cap = std::min<int64_t>(std::max<int64_t>(4096, 4 * (int64_t)nq), std::max<int64_t>(total_pref, 1));
     pl->seg_cap = pl->nseg == 1 ? (int)total_cap : (int)std::max<int64_t>(256, 2 * total_cap / pl->nseg);
@@ -1256,13 +1324,13 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
     const SeedQ* d_q = pl->d_q.as<SeedQ>();
     const uint8_t* d_reads = pl->d_reads.as<uint8_t>();
     ALFA_HIP(hipMemsetAsync(d_cnt, 0, 4 * (size_t)pl->nseg, st));
-    ALFA_HIP(hipMemsetAsync(d_tot + nq, 0, 8, st));
+    ALFA_HIP(hipMemsetAsync(d_tot, 0, 8 * ((size_t)nq + 1), st));       // the persistent kernel accumulates per-read totals
     ALFA_HIP(hipEventRecord(pl->ev0, st));
     if (pl->persistent) {
         // one workgroup per CU, the 10-mer bitmap + one read slice per wave in LDS
         const size_t lds = (size_t)KBIT_BYTES + (size_t)PWAVES * (2 * pl->stride + WQ_BYTES);      // read bytes + 2-bit codes + survivor queue per wave
-        hipLaunchKernelGGL(smam_count_kernel, dim3(pl->nseg), dim3(PBLOCK), lds, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec>(), d_cnt,
-                           pl->seg_cap, nq, pl->stride);
+        hipLaunchKernelGGL(smam_count_kernel, dim3(pl->nseg), dim3(PBLOCK), lds, st, X, d_q, d_reads, (unsigned long long*)d_tot,
+                           pl->d_work.as<WorkRec>(), d_cnt, pl->seg_cap, nq, pl->stride, pl->d_q3.as<Q3>());
     } else if (pl->mem_type == ALFA_SEED_SMAM) {
         hipLaunchKernelGGL(smam_count_simple_kernel, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec>(),
                            d_cnt, pl->seg_cap, lds_p);
@@ -1334,7 +1402,7 @@ int plan_fetch(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_match** matches, int64_t*
 
 void plan_release(alfa_seed_plan* pl) {
     pl->d_reads.release(); pl->d_q.release(); pl->d_tot.release(); pl->d_base.release(); pl->d_work.release(); pl->d_out.release();
-    pl->d_tmp.release(); pl->d_scr.release(); pl->d_cnt.release();
+    pl->d_tmp.release(); pl->d_scr.release(); pl->d_cnt.release(); pl->d_q3.release();
     if (pl->ev0) { (void)hipEventDestroy(pl->ev0); (void)hipEventDestroy(pl->ev1); pl->ev0 = pl->ev1 = nullptr; }
 }
 
