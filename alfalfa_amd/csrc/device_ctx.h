@@ -51,6 +51,10 @@ struct Ctx {
     hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t side_ev[NSIDE] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr;
+    // lazy join (alfa_set_lazy_join): launches leave their side chains unjoined so that successive batches overlap; the
+    // main stream waits for them before anything that consumes results (fetch, sync, timer stop, free)
+    bool lazy_join = false, sides_pending = false;
+    int join_sides();
     // staging
     DevBuf d_in, d_in2, d_tasks, d_out, d_out2, d_scratch, d_z, d_cnt, d_off, d_ivl;
     PinBuf h_in, h_in2, h_tasks, h_out, h_out2;

@@ -62,6 +62,13 @@ int Ctx::ensure(int dev) {
     return ALFA_OK;
 }
 
+int Ctx::join_sides() {
+    if (!sides_pending) return ALFA_OK;
+    for (int k = 0; k < NSIDE; ++k) ALFA_HIP(hipStreamWaitEvent(stream, side_ev[k], 0));
+    sides_pending = false;
+    return ALFA_OK;
+}
+
 Ctx* thread_ctx(int device) {
     // one context per (thread, device); contexts live until the thread exits
     thread_local std::map<int, std::unique_ptr<Ctx>> ctxs;

@@ -975,10 +975,9 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
         o += bc[7];
     }
     const int nside = used < alfa::Ctx::NSIDE ? used : alfa::Ctx::NSIDE;
-    for (int k = 0; k < nside; ++k) {
-        (void)hipEventRecord(cx->side_ev[k], cx->side[k]);
-        (void)hipStreamWaitEvent(st, cx->side_ev[k], 0);
-    }
+    for (int k = 0; k < nside; ++k) (void)hipEventRecord(cx->side_ev[k], cx->side[k]);
+    if (nside > 0) cx->sides_pending = true;
+    if (!cx->lazy_join) (void)cx->join_sides();
     if (bc[8])
         hipLaunchKernelGGL((ksw_lane_kernel<MODE, false>), dim3((bc[8] + 63) / 64), dim3(64), 0, st, d_t + o, bc[8], d_seq, d_prm, d_out,
                            b->d_eh.as<int2>(), d_z, d_cig, d_ncig, 0);
@@ -1124,6 +1123,8 @@ int fetch_batch(alfa_dp_batch* b, Ctx* cx, void* out_host, const int* ids, std::
     const int n = b->n;
     if (n == 0) return ALFA_OK;
     hipStream_t st = cx->stream;
+    int jrc = cx->join_sides();
+    if (jrc) return jrc;
     ALFA_HIP(hipMemcpyAsync(b->h_out.p, b->d_out.p, b->out_bytes, hipMemcpyDeviceToHost, st));
     if (b->mode == MODE_GLOBAL)
         ALFA_HIP(hipMemcpyAsync(b->h_cig.p, b->d_cig.p, 4 * (size_t)b->cig_words + 4 * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -1292,7 +1293,16 @@ int alfa_sync(int device) {
     Ctx* cx;
     int rc = current_ctx(&cx, device);
     if (rc) return rc;
+    if ((rc = cx->join_sides())) return rc;
     ALFA_HIP(hipStreamSynchronize(cx->stream));
+    return ALFA_OK;
+}
+int alfa_set_lazy_join(int device, int on) {
+    Ctx* cx;
+    int rc = current_ctx(&cx, device);
+    if (rc) return rc;
+    if (!on && (rc = cx->join_sides())) return rc;
+    cx->lazy_join = on != 0;
     return ALFA_OK;
 }
 int alfa_timer_start(int device) {
@@ -1306,6 +1316,7 @@ int alfa_timer_stop(int device, double* ms) {
     Ctx* cx;
     int rc = current_ctx(&cx, device);
     if (rc) return rc;
+    if ((rc = cx->join_sides())) return rc;
     ALFA_HIP(hipEventRecord(cx->ev[1], cx->stream));
     ALFA_HIP(hipEventSynchronize(cx->ev[1]));
     float f = 0;

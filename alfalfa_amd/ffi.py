@@ -460,6 +460,10 @@ def sync(device=0):
     check(lib().alfa_sync(int(device)))
 
 
+def set_lazy_join(device=0, on=True):
+    check(lib().alfa_set_lazy_join(int(device), int(bool(on))))
+
+
 def timer_start(device=0):
     check(lib().alfa_timer_start(int(device)))
 

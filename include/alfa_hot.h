@@ -182,6 +182,11 @@ void    alfa_seed_plan_free(alfa_seed_plan*);
 
 /* wait for everything enqueued on the calling thread's stream for `device` */
 int     alfa_sync(int device);
+/* DP batches run their kernel bins as independent chains on side streams.  By default a launch joins them back into the
+ * calling thread's stream before it returns (so alfa_dp_batch_kernel_ms brackets exactly that batch); with lazy join on,
+ * the join is deferred to the next fetch / alfa_sync / alfa_timer_stop so that successive batches overlap.  No counterpart
+ * in the reference. */
+int     alfa_set_lazy_join(int device, int on);
 /* HIP-event stopwatch on that same stream: start, (launch...), stop -> elapsed device milliseconds */
 int     alfa_timer_start(int device);
 int     alfa_timer_stop(int device, double* ms);
