@@ -356,6 +356,15 @@ def main():
         if "reference_cpu" in e2e and "alfalfa_amd_gpu" in e2e:
             e2e["sam_identical"] = e2e["reference_cpu"]["sam_md5"] == e2e["alfalfa_amd_gpu"]["sam_md5"]
 
+    # the baseline the north star asks for: the reference's own CPU path, multithreaded on this box's host cores.  It can
+    # only be timed as the whole command line (it has no hot-path-only mode), on the bounded sample of --e2e-reads reads;
+    # the scalar port of the hot path alone (1 core) stays beside it.
+    if e2e and e2e.get("reference_cpu", {}).get("rc") == 0:
+        port = cpu
+        cpu = {"value": e2e["reference_cpu"]["reads_per_s"], "unit": "reads/s", "cores": args.e2e_threads, "kind": "reference",
+               "sample": "%d reads of the same workload through the compiled reference (oracle/_ref/alfalfa align -t %d), whole command "
+                         "line FASTQ -> SAM, %.1f s wall" % (args.e2e_reads, args.e2e_threads, e2e["reference_cpu"]["seconds"]),
+               "hot_path_port_1core": port}
     dp_ms = sum(ext_ms) + sum(nw_ms) + sum(gl_ms)
     out = {
         "metric": "mapped reads/sec (hot path: SMAM seeds both strands + banded DP) + banded-DP GCUPS",
