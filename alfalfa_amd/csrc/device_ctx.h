@@ -47,9 +47,10 @@ struct Ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // side streams: independent kernel chains of one batch (one per kernel bin) fork from `stream` and join it again,
     // so that a bin holding a handful of long tasks does not serialise behind (or in front of) the others
-    static constexpr int NSIDE = 6;
-    hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t side_ev[NSIDE] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int NSIDE = 8;
+    hipStream_t side[NSIDE] = {};
+    hipEvent_t side_ev[NSIDE] = {};
+    hipEvent_t fill_ev[3] = {};      // a group bin's fill kernel is done: its two backtrack classes may run side by side
     hipEvent_t fork_ev = nullptr;
     // lazy join (alfa_set_lazy_join): launches leave their side chains unjoined so that successive batches overlap; the
     // main stream waits for them before anything that consumes results (fetch, sync, timer stop, free)

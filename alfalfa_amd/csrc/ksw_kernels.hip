@@ -617,7 +617,6 @@ __global__ void ksw_backtrack_kernel(const DevTask* __restrict__ tasks, int ntas
 // Same walk for small tasks (direction matrix of at most ZC bytes): every lane first copies its task's matrix into its own
 // LDS slice with independent 16-byte loads, then walks it there -- ~50 dependent LDS reads instead of ~50 dependent HBM reads.
 constexpr int ZC = 512;        // 64 tasks per workgroup
-constexpr int ZC2 = 2048;      // 16 tasks per workgroup
 template <int ZC, int TPB>
 __global__ __launch_bounds__(TPB) void ksw_backtrack_lds_kernel(const DevTask* __restrict__ tasks, int ntask, const uint8_t* __restrict__ zbuf,
                                                                uint32_t* __restrict__ cig, int32_t* __restrict__ ncig, int ROWB) {
@@ -837,7 +836,7 @@ struct alfa_dp_batch {
     std::vector<DevTask> ht;        // device order, .orig already remapped to the dense output index
     std::vector<int> dense_of;      // device order -> caller index
     int bin_cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // lane kernel (qlen <= 30, 62, 126), group kernel C=1,2,4, wave kernel C=2,4, generic
-    int nbig[3] = {0, 0, 0}, nbig2[3] = {0, 0, 0};   // group bins: tasks whose direction matrix exceeds ZC / ZC2 bytes (prefixes: sorted by tlen)
+    int nbig[3] = {0, 0, 0};        // group bins: tasks whose direction matrix exceeds ZC bytes (a prefix: sorted by tlen)
     int64_t cig_words = 0, cells = 0, zbytes = 0, eh_items = 0;
     size_t seq_bytes = 0, out_bytes = 0;
     alfa::DevBuf d_seq, d_tasks, d_out, d_z, d_cig, d_eh;
@@ -934,49 +933,54 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
     }
     // bands of up to 16 / 32 / 64 diagonals: 16 lanes per task
     // Every bin is an independent chain (fill kernel -> backtrack): the chains fork onto side streams and join again.
-    // Tasks of a bin are ordered by tlen, longest first: the first nbig2 direction matrices exceed ZC2 bytes (backtrack walks
-    // HBM), the next ones up to nbig exceed ZC (LDS slices of ZC2), the rest fit ZC.
+    // Tasks of a bin are ordered by tlen, longest first: the first nbig direction matrices exceed ZC bytes (their backtrack
+    // walks HBM), the rest fit ZC (LDS slices); the two backtrack classes of a bin run side by side.
+    // streams: 0-2 group bins, 3-4 wave bins, 5-7 the LDS backtracks of the group bins
     (void)hipEventRecord(cx->fork_ev, st);
-    int used = 0;
-    auto side = [&](int n) -> hipStream_t {
-        if (n <= 0) return st;
-        hipStream_t s2 = cx->side[used % alfa::Ctx::NSIDE];
-        if (used < alfa::Ctx::NSIDE) (void)hipStreamWaitEvent(s2, cx->fork_ev, 0);
-        ++used;
-        return s2;
+    bool used[alfa::Ctx::NSIDE] = {};
+    auto side = [&](int k) -> hipStream_t {
+        if (!used[k]) { (void)hipStreamWaitEvent(cx->side[k], cx->fork_ev, 0); used[k] = true; }
+        return cx->side[k];
     };
     for (int g = 0; g < 3; ++g) {
-        const int n = bc[3 + g], nbig = b->nbig[g], nbig2 = b->nbig2[g], rowb = GL << g;
-        hipStream_t s2 = side(n);
-        if (g == 0) launch_group<MODE, 1>(s2, d_t + o, n, d_seq, d_prm, d_out, d_z);
-        else if (g == 1) launch_group<MODE, 2>(s2, d_t + o, n, d_seq, d_prm, d_out, d_z);
-        else launch_group<MODE, 4>(s2, d_t + o, n, d_seq, d_prm, d_out, d_z);
-        if (MODE == MODE_GLOBAL && nbig2 > 0)
-            hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((nbig2 + 63) / 64), dim3(64), 0, s2, d_t + o, nbig2, d_z, d_cig, d_ncig, rowb);
-        if (MODE == MODE_GLOBAL && nbig > nbig2)
-            hipLaunchKernelGGL((ksw_backtrack_lds_kernel<ZC2, 16>), dim3((nbig - nbig2 + 15) / 16), dim3(16), 0, s2, d_t + o + nbig2,
-                               nbig - nbig2, d_z, d_cig, d_ncig, rowb);
-        if (MODE == MODE_GLOBAL && n > nbig)
-            hipLaunchKernelGGL((ksw_backtrack_lds_kernel<ZC, 64>), dim3((n - nbig + 63) / 64), dim3(64), 0, s2, d_t + o + nbig, n - nbig, d_z,
-                               d_cig, d_ncig, rowb);
+        const int n = bc[3 + g], nbig = b->nbig[g], rowb = GL << g;
+        if (n > 0) {
+            hipStream_t s2 = side(g);
+            if (g == 0) launch_group<MODE, 1>(s2, d_t + o, n, d_seq, d_prm, d_out, d_z);
+            else if (g == 1) launch_group<MODE, 2>(s2, d_t + o, n, d_seq, d_prm, d_out, d_z);
+            else launch_group<MODE, 4>(s2, d_t + o, n, d_seq, d_prm, d_out, d_z);
+            if (MODE == MODE_GLOBAL) {
+                if (n > nbig) {
+                    hipStream_t s3 = nbig > 0 ? side(5 + g) : s2;
+                    if (s3 != s2) { (void)hipEventRecord(cx->fill_ev[g], s2); (void)hipStreamWaitEvent(s3, cx->fill_ev[g], 0); }
+                    hipLaunchKernelGGL((ksw_backtrack_lds_kernel<ZC, 64>), dim3((n - nbig + 63) / 64), dim3(64), 0, s3, d_t + o + nbig, n - nbig,
+                                       d_z, d_cig, d_ncig, rowb);
+                }
+                if (nbig > 0)
+                    hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((nbig + 63) / 64), dim3(64), 0, s2, d_t + o, nbig, d_z, d_cig, d_ncig, rowb);
+            }
+        }
         o += n;
     }
     // bands of up to 128 / 256 diagonals: a whole wavefront per task
-    {
-        hipStream_t s2 = side(bc[6]);
+    if (bc[6]) {
+        hipStream_t s2 = side(3);
         launch_wave<MODE, 2>(s2, d_t + o, bc[6], d_seq, d_prm, d_out, d_z);
-        if (MODE == MODE_GLOBAL && bc[6])
+        if (MODE == MODE_GLOBAL)
             hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[6] + 63) / 64), dim3(64), 0, s2, d_t + o, bc[6], d_z, d_cig, d_ncig, 64 * 2);
-        o += bc[6];
-        s2 = side(bc[7]);
-        launch_wave<MODE, 4>(s2, d_t + o, bc[7], d_seq, d_prm, d_out, d_z);
-        if (MODE == MODE_GLOBAL && bc[7])
-            hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[7] + 63) / 64), dim3(64), 0, s2, d_t + o, bc[7], d_z, d_cig, d_ncig, 64 * 4);
-        o += bc[7];
     }
-    const int nside = used < alfa::Ctx::NSIDE ? used : alfa::Ctx::NSIDE;
-    for (int k = 0; k < nside; ++k) (void)hipEventRecord(cx->side_ev[k], cx->side[k]);
-    if (nside > 0) cx->sides_pending = true;
+    o += bc[6];
+    if (bc[7]) {
+        hipStream_t s2 = side(4);
+        launch_wave<MODE, 4>(s2, d_t + o, bc[7], d_seq, d_prm, d_out, d_z);
+        if (MODE == MODE_GLOBAL)
+            hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[7] + 63) / 64), dim3(64), 0, s2, d_t + o, bc[7], d_z, d_cig, d_ncig, 64 * 4);
+    }
+    o += bc[7];
+    bool any = false;
+    for (int k = 0; k < alfa::Ctx::NSIDE; ++k)
+        if (used[k]) { (void)hipEventRecord(cx->side_ev[k], cx->side[k]); any = true; }
+    if (any) cx->sides_pending = true;
     if (!cx->lazy_join) (void)cx->join_sides();
     if (bc[8])
         hipLaunchKernelGGL((ksw_lane_kernel<MODE, false>), dim3((bc[8] + 63) / 64), dim3(64), 0, st, d_t + o, bc[8], d_seq, d_prm, d_out,
@@ -990,7 +994,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
     b->mode = mode; b->n = n; b->device = cx->device; b->launched = false; b->kernel_ms = 0;
     b->cig_words = b->cells = b->zbytes = b->eh_items = 0;
     for (int k = 0; k < 9; ++k) b->bin_cnt[k] = 0;
-    for (int k = 0; k < 3; ++k) b->nbig[k] = b->nbig2[k] = 0;
+    for (int k = 0; k < 3; ++k) b->nbig[k] = 0;
     b->ht.resize((size_t)n);
     b->dense_of.resize((size_t)n);
     if (!b->ev0) { ALFA_HIP(hipEventCreate(&b->ev0)); ALFA_HIP(hipEventCreate(&b->ev1)); }
@@ -1013,7 +1017,6 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         bins[i] = bin;
         b->bin_cnt[bin]++;
         if (bin >= 3 && bin <= 5 && (int64_t)x.tlen * (GL << (bin - 3)) > ZC) b->nbig[bin - 3]++;
-        if (bin >= 3 && bin <= 5 && (int64_t)x.tlen * (GL << (bin - 3)) > ZC2) b->nbig2[bin - 3]++;
         seq_bytes += (size_t)x.qlen + (size_t)x.tlen;
     }
     // order: by bin; inside a bin the most work first, so that the 64 tasks of a lane-kernel wave (and co-resident waves of the
