@@ -37,7 +37,7 @@ struct alfa_index {
     int device = 0;
     int64_t N = 0, n = 0, K = 1, logN = 0, NKm1 = 0, nM = 0;
     int has_child = 0, has_suflink = 0, has_kmer = 0;
-    alfa::DevBuf S, SA, LCP, Midx, Mval, CHILD, KMR, KMR2, KBIT;
+    alfa::DevBuf S, SA, LCP, Midx, Mval, CHILD, KMR, KMR2, KBIT, ISA;
 };
 
 namespace {
@@ -56,8 +56,10 @@ struct DIdx {
     const uint2* __restrict__ KMR;      // the reference's 10-mer table {left, right}
     const uint4* __restrict__ KMR2;     // derived at upload: {left, right, SA[left], right == left ? S[SA[left]+10..+13] : SA[left+1]}
     const uint32_t* __restrict__ KBIT;  // derived at upload: bit per 10-mer, set when right > 0 (128 KiB: stays in L2)
+    const int32_t* __restrict__ ISA;    // suffix-link indexes only
     int64_t N;
     int32_t n, nM, K, has_kmer, has_child;
+    int32_t logN, NKm1;
 };
 
 struct SeedQ {          // one sparseSA::SMAM(P, ...) call
@@ -1088,6 +1090,95 @@ __global__ void emit2_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t
                                Q.max_count, step, o);
 }
 
+// ---------------------------------------------------------------- SMAM on a suffix-link index (--suflink)
+// expand_link src/sparseSA.h:223-239, suffixlink src/sparseSA.cpp:849-855
+__device__ bool d_suffixlink(const DIdx& X, IvalD& m) {
+    m.depth -= X.K;
+    if (m.depth <= 0) return false;
+    const int64_t is = (int64_t)X.SA[m.start] / X.K + 1, ie = (int64_t)X.SA[m.end] / X.K + 1;
+    if (is >= X.n || ie >= X.n) return false;          // (the reference reads one past its ISA here)
+    int start = X.ISA[is], end = X.ISA[ie];
+    const int64_t thresh = 2 * (int64_t)m.depth * X.logN;
+    int64_t exp = 0;
+    while (start > 0 && d_lcp(X, start) >= m.depth) { if (++exp >= thresh) return false; --start; }
+    while (end < X.NKm1 && d_lcp(X, end + 1) >= m.depth) { if (++exp >= thresh) return false; ++end; }
+    m.start = start; m.end = end;
+    return true;
+}
+
+// With suffix links the prefixes of one phase k form a chain (findSMAM :1063-1114: the interval reached for one prefix is
+// carried, through sparseQ suffix links, into the next), so the unit of parallel work is (read, phase): lane k of the read's
+// workgroup walks phase k.  Pass 1 (EMIT = false) counts per phase; pass 2 re-walks and writes at the scanned offsets.
+template <bool EMIT>
+__global__ __launch_bounds__(SEED_BLOCK) void smam_suflink_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
+                                                                 int64_t* __restrict__ read_total, int32_t* __restrict__ phase_cnt,
+                                                                 const int64_t* __restrict__ read_base, alfa_match* __restrict__ out,
+                                                                 int64_t out_cap, int nq, int lds_p) {
+    extern __shared__ uint8_t smem[];
+    __shared__ int sh_scan[SEED_BLOCK / 64];
+    const int r = blockIdx.x;
+    const SeedQ Q = qs[r];
+    const int tid = threadIdx.x;
+    PatD P;
+    P.len = Q.plen;
+    if (lds_p) {
+        for (int i = tid; i < Q.plen; i += SEED_BLOCK) smem[PADB + i] = reads[Q.poff + i];
+        __syncthreads();
+        P.p = smem + PADB;
+    } else {
+        P.p = reads + Q.poff;
+    }
+    if (EMIT && read_base[nq] > out_cap) return;
+    const int K = X.K;
+    const int step = Q.sparse_q * K;
+    const int min_lenK = Q.min_len - (step - 1);
+    const int minMin_len = Q.sparse_q > 1 ? Q.min_len - K : Q.min_len;
+    const int maxCount = Q.sparse_q * Q.max_count;
+    const bool active = Q.min_len >= K;                       // sparseSA::SMAM :1122
+    int running = 0;
+    for (int kb = 0; kb < K; kb += SEED_BLOCK) {
+        const int k = kb + tid;
+        int cnt = 0;
+        int my_off = 0;
+        if (EMIT) {
+            const int c = (active && k < K) ? phase_cnt[(int64_t)r * K + k] : 0;
+            int total;
+            my_off = running + block_excl_scan(c, sh_scan, total);
+            running += total;
+        }
+        if (active && k < K) {
+            alfa_match* o = EMIT ? out + read_base[r] + my_off : nullptr;
+            IvalD xmi = {0, X.n - 1, 0};
+            int prefix = k;
+            while (prefix <= Q.plen - min_lenK) {
+                traverse_any(X, P, prefix, xmi, Q.plen);
+                if (xmi.depth <= 1) { xmi = {0, X.n - 1, 0}; prefix += step; continue; }
+                if (xmi.depth >= min_lenK && (xmi.end - xmi.start + 1) <= maxCount) {
+                    for (int i = xmi.start; i <= xmi.end; ++i) {
+                        int64_t mr; int mq, ml;
+                        if (lmax_strict(X, P, prefix, (int64_t)X.SA[i], xmi.depth, minMin_len, step, mr, mq, ml)) {
+                            if (EMIT) { alfa_match m; m.ref = mr; m.query = mq; m.len = ml; o[cnt] = m; }
+                            ++cnt;
+                        }
+                    }
+                }
+                prefix += step;
+                int i = 0;
+                bool ok = true;
+                while (i < Q.sparse_q && (ok = d_suffixlink(X, xmi))) ++i;
+                if (!ok) xmi = {0, X.n - 1, 0};
+            }
+        }
+        if (!EMIT) {
+            if (active && k < K) phase_cnt[(int64_t)r * K + k] = cnt;
+            int total;
+            (void)block_excl_scan(cnt, sh_scan, total);
+            running += total;
+        }
+    }
+    if (!EMIT && tid == 0) read_total[r] = running;
+}
+
 // number of prefix queries of one SMAM call (mirrors findSMAM's loop bounds, sparseSA.cpp:1066-1072)
 int64_t count_prefixes(int64_t K, int plen, int min_len, int sparse_q) {
     if (min_len < K) return 0;                       // sparseSA.cpp:1122
@@ -1137,13 +1228,14 @@ int alfa_index_upload(const alfa_index_view* v, int device, alfa_index** out) {
     alfa_index* ix = new alfa_index();
     ix->device = device;
     ix->N = v->N; ix->n = v->n; ix->K = v->K; ix->logN = v->logN; ix->NKm1 = v->NKm1; ix->nM = v->nM;
-    ix->has_child = v->has_child && v->CHILD; ix->has_suflink = v->has_suflink; ix->has_kmer = v->has_kmer && v->KMR;
+    ix->has_child = v->has_child && v->CHILD; ix->has_suflink = v->has_suflink && v->ISA; ix->has_kmer = v->has_kmer && v->KMR;
     int rc = ALFA_OK;
     if ((rc = upload_padded(ix->S, v->S, (size_t)v->N)) || (rc = upload(ix->SA, v->SA, 4 * (size_t)v->n)) ||
         (rc = upload(ix->LCP, v->LCP, (size_t)v->n)) || (rc = upload(ix->Midx, v->LCP_M_idx, 8 * (size_t)v->nM)) ||
         (rc = upload(ix->Mval, v->LCP_M_val, 4 * (size_t)v->nM)) ||
         (ix->has_child && (rc = upload(ix->CHILD, v->CHILD, 4 * (size_t)v->n))) ||
-        (ix->has_kmer && (rc = upload(ix->KMR, v->KMR, 8 * (size_t)TABLE)))) {
+        (ix->has_kmer && (rc = upload(ix->KMR, v->KMR, 8 * (size_t)TABLE))) ||
+        (ix->has_suflink && v->ISA && (rc = upload(ix->ISA, v->ISA, 4 * (size_t)v->n)))) {
         alfa_index_free(ix);
         return rc;
     }
@@ -1171,7 +1263,7 @@ int alfa_index_upload(const alfa_index_view* v, int device, alfa_index** out) {
 void alfa_index_free(alfa_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    ix->S.release(); ix->SA.release(); ix->LCP.release(); ix->Midx.release(); ix->Mval.release(); ix->CHILD.release(); ix->KMR.release(); ix->KMR2.release(); ix->KBIT.release();
+    ix->S.release(); ix->SA.release(); ix->LCP.release(); ix->Midx.release(); ix->Mval.release(); ix->CHILD.release(); ix->KMR.release(); ix->KMR2.release(); ix->KBIT.release(); ix->ISA.release();
     delete ix;
 }
 
@@ -1186,6 +1278,7 @@ struct alfa_seed_plan {
     size_t read_bytes = 0;
     int nseg = 1, seg_cap = 0;   // work list: nseg segments of seg_cap records (persistent SMAM kernel: one per workgroup)
     bool persistent = false;
+    bool suflink = false;        // SMAM on a suffix-link index: (read, phase) chains, no work list
     int stride = 0;              // persistent kernel: LDS bytes per wave for its read
     int64_t out_cap = 0;
     alfa::DevBuf d_reads, d_q, d_tot, d_base, d_work, d_cnt, d_out, d_tmp, d_scr, d_q3;
@@ -1204,7 +1297,8 @@ DIdx make_didx(const alfa_index* ix) {
     DIdx X;
     X.S = ix->S.as<uint8_t>() + PADB; X.SA = ix->SA.as<uint32_t>(); X.LCP = ix->LCP.as<uint8_t>();
     X.Midx = ix->Midx.as<int64_t>(); X.Mval = ix->Mval.as<int32_t>(); X.CHILD = ix->CHILD.as<int32_t>();
-    X.KMR = ix->KMR.as<uint2>(); X.KMR2 = ix->KMR2.as<uint4>(); X.KBIT = ix->KBIT.as<uint32_t>();
+    X.KMR = ix->KMR.as<uint2>(); X.KMR2 = ix->KMR2.as<uint4>(); X.KBIT = ix->KBIT.as<uint32_t>(); X.ISA = ix->ISA.as<int32_t>();
+    X.logN = (int32_t)ix->logN; X.NKm1 = (int32_t)ix->NKm1;
     X.N = ix->N; X.n = (int32_t)ix->n; X.nM = (int32_t)ix->nM; X.K = (int32_t)ix->K; X.has_kmer = ix->has_kmer; X.has_child = ix->has_child;
     return X;
 }
@@ -1214,7 +1308,8 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
         return alfa::fail(ALFA_ENOTSUP, "seed type has no HIP kernel (SMAM, MEM and SMEM do; SMEMP is unreachable from the reference's CLI)");
     if (!ix->has_child && mem_type == ALFA_SEED_SMEM)
         return alfa::fail(ALFA_ENOTSUP, "SMEM needs an index with a child table (the reference calls traverse_faster unconditionally)");
-    if (ix->has_suflink) return alfa::fail(ALFA_ENOTSUP, "suffix-link (--suflink) indexes are not supported by the HIP seed kernels");
+    if (ix->has_suflink && mem_type == ALFA_SEED_MEM)
+        return alfa::fail(ALFA_ENOTSUP, "MEM on a suffix-link (--suflink) index has no HIP kernel (SMAM and SMEM do)");
     pl->ix = ix; pl->nq = nq; pl->launched = false; pl->mem_type = mem_type;
     pl->work_rec = mem_type == ALFA_SEED_SMAM ? sizeof(WorkRec) : sizeof(WorkRec2);
     if (!pl->ev0) { ALFA_HIP(hipEventCreate(&pl->ev0)); ALFA_HIP(hipEventCreate(&pl->ev1)); }
@@ -1280,7 +1375,9 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
         if (!pl->lds_tab && (rc = pl->d_scr.reserve(4 * (size_t)scr_ints + 64))) return rc;
     }
     static const bool force_simple = getenv("ALFA_SEED_SIMPLE") != nullptr;   // A/B switch for profiling
-    pl->persistent = mem_type == ALFA_SEED_SMAM && ix->has_child && ix->has_kmer && !force_simple && magic_ok;
+    pl->suflink = mem_type == ALFA_SEED_SMAM && ix->has_suflink;
+    pl->persistent = mem_type == ALFA_SEED_SMAM && ix->has_child && ix->has_kmer && !force_simple && magic_ok && !pl->suflink;
+    if (pl->suflink && (rc = pl->d_scr.reserve(4 * (size_t)nq * (size_t)ix->K + 64))) return rc;
     pl->nseg = 1;
     if (pl->persistent) {
         static int n_cu[64] = {0};
@@ -1326,7 +1423,10 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
     ALFA_HIP(hipMemsetAsync(d_cnt, 0, 4 * (size_t)pl->nseg, st));
     ALFA_HIP(hipMemsetAsync(d_tot, 0, 8 * ((size_t)nq + 1), st));       // the persistent kernel accumulates per-read totals
     ALFA_HIP(hipEventRecord(pl->ev0, st));
-    if (pl->persistent) {
+    if (pl->suflink) {
+        hipLaunchKernelGGL(smam_suflink_kernel<false>, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot, pl->d_scr.as<int32_t>(),
+                           (const int64_t*)nullptr, (alfa_match*)nullptr, (int64_t)0, nq, lds_p);
+    } else if (pl->persistent) {
         // one workgroup per CU, the 10-mer bitmap + one read slice per wave in LDS
         const size_t lds = (size_t)KBIT_BYTES + (size_t)PWAVES * (2 * pl->stride + WQ_BYTES);      // read bytes + 2-bit codes + survivor queue per wave
         hipLaunchKernelGGL(smam_count_kernel, dim3(pl->nseg), dim3(PBLOCK), lds, st, X, d_q, d_reads, (unsigned long long*)d_tot,
@@ -1348,7 +1448,10 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
     size_t tb = pl->tmp_bytes;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_tmp.p, tb, d_tot, d_base, nq + 1, st));
     const dim3 eg((pl->seg_cap + 127) / 128, pl->nseg), eb(128);
-    if (pl->mem_type == ALFA_SEED_SMAM)
+    if (pl->suflink)
+        hipLaunchKernelGGL(smam_suflink_kernel<true>, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot, pl->d_scr.as<int32_t>(),
+                           (const int64_t*)d_base, pl->d_out.as<alfa_match>(), pl->out_cap, nq, lds_p);
+    else if (pl->mem_type == ALFA_SEED_SMAM)
         hipLaunchKernelGGL(smam_emit_kernel, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec>(), d_cnt, pl->seg_cap,
                            pl->d_out.as<alfa_match>(), pl->out_cap);
     else if (pl->mem_type == ALFA_SEED_MEM)

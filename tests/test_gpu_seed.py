@@ -130,13 +130,32 @@ def test_index_without_child_table(gpu, mt):
         assert _check(hidx, didx, reads, 30, 1000, 1, mt) > 50
 
 
+@pytest.mark.parametrize("K", [1, 3, 12])
+def test_smam_suffix_link_index(gpu, K):
+    """--suflink index: the prefixes of a phase form a chain through suffix links (findSMAM src/sparseSA.cpp:1085-1112)"""
+    rng = np.random.default_rng(300 + K)
+    ref = seqgen.rand_ref(rng, 200000)
+    rep = ref[5000:9000]
+    ref = ref + rep + b"acgt" * 100 + rep
+    hidx = ffi.HostIndex.build_mem(["x"], [ref], K=K, suflink=True)
+    didx = ffi.DeviceIndex(hidx, gpu)
+    reads = seqgen.sim_reads(rng, ref, 300, 80, 600, 0.03)
+    reads += [b"", b"acgt" * 30, b"n" * 50, rep[100:400]]
+    ml = [seqgen.seed_params(K, len(r))[0] for r in reads]
+    sq = [seqgen.seed_params(K, len(r))[1] for r in reads]
+    assert _check(hidx, didx, reads, ml, 10000, sq) > 200
+    _check(hidx, didx, reads, max(20, K + 10), 100000, 1)
+    _check(hidx, didx, reads, 25, 3, 1)
+    assert _check(hidx, didx, reads, ml, 10000, sq, ffi.SEED_SMEM, 10) > 100      # SMEM does not use the links
+
+
 def test_unsupported_types_fail_loudly(gpu):
     rng = np.random.default_rng(5)
     ref = seqgen.rand_ref(rng, 20000)
     hidx = ffi.HostIndex.build_mem(["x"], [ref], K=3, suflink=True)
     didx = ffi.DeviceIndex(hidx, gpu)
     with pytest.raises(ffi.AlfaError):
-        didx.seed_batch(ffi.SEED_SMAM, ffi.make_seed_queries([ref[:100]], 40, 100, 1))
+        didx.seed_batch(ffi.SEED_MEM, ffi.make_seed_queries([ref[:100]], 40, 100, 1))
     hidx2 = ffi.HostIndex.build_mem(["x"], [ref], K=3)
     didx2 = ffi.DeviceIndex(hidx2, gpu)
     with pytest.raises(ffi.AlfaError):
