@@ -41,12 +41,15 @@ def test_gpu_mapper_vs_oracle_mapper_synthetic(gpu):
     fq("long.fq", seqgen.sim_reads(rng, cat, 300, 2000, 8000, 0.10))
     subprocess.run([M.GPU_EXE, "index", "-r", "syn.fa", "-p", "syn12", "-s", "12"], cwd=d, check=True, stdout=subprocess.DEVNULL,
                    stderr=subprocess.DEVNULL)
-    for tag, args in (("short", ["-0", "short.fq"]), ("long", ["-0", "long.fq", "-e", "0.12"]), ("longdef", ["-0", "long.fq"]),
+    subprocess.run([M.GPU_EXE, "index", "-r", "syn.fa", "-p", "syn12sl", "-s", "12", "--suflink"], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+    for tag, args in (("short", ["-0", "short.fq"]), ("short_suflink", ["-i", "syn12sl", "-0", "short.fq"]), ("long", ["-0", "long.fq", "-e", "0.12"]), ("longdef", ["-0", "long.fq"]),
                       ("short_mem", ["-0", "short.fq", "--seed", "MEM"]), ("long_psmem", ["-0", "long.fq", "-e", "0.12", "--seed", "PSMEM"])):
         outs = []
         for exe, thr in ((M.GPU_EXE, "4"), (M.CPU_EXE, "16")):
             out = os.path.join(d, "syn_%s_%s.sam" % (tag, os.path.basename(exe)))
-            p = subprocess.run([exe, "align", "-i", "syn12", "-o", out, "-t", thr] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            idx = [] if "-i" in args else ["-i", "syn12"]
+            p = subprocess.run([exe, "align"] + idx + ["-o", out, "-t", thr] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             assert p.returncode == 0, p.stderr.decode()[-2000:]
             outs.append(M.sam_body(out))
         assert outs[0] == outs[1], tag
