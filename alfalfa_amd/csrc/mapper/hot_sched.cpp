@@ -9,7 +9,39 @@
 #include <cstring>
 #include <stdexcept>
 
+#if !defined(__x86_64__)
+#error "hot_sched.cpp: the fiber switch is written for x86-64 (System V ABI)"
+#endif
+
+// void alfa_ctx_switch(void** save_sp, void* load_sp): saves the callee-saved registers on the current stack, stores the
+// stack pointer, loads the other stack pointer and restores that context's registers; returns on the other stack.
+extern "C" void alfa_ctx_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl alfa_ctx_switch
+    .type alfa_ctx_switch,@function
+alfa_ctx_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size alfa_ctx_switch, .-alfa_ctx_switch
+)");
+
 namespace alfa {
+
+static thread_local HotSched* tl_sched = nullptr;      // the scheduler whose fibers run on this thread
 
 HotSched::HotSched(const HotOps& ops, const alfa_dp_params& prm, size_t stack_bytes) : ops_(ops), prm_(prm), stack_bytes_(stack_bytes) {}
 
@@ -32,17 +64,32 @@ HotSched::~HotSched() {
         if (f.stack) munmap(f.stack, stack_bytes_);
 }
 
-void HotSched::trampoline(unsigned lo, unsigned hi) {
-    HotSched* self = (HotSched*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+void HotSched::fiber_entry() {
+    HotSched* self = tl_sched;
+    {
+        Fiber& f = self->fibers_[self->current_];
+        (*self->job_)(f.job);
+        f.done = true;
+    }
     Fiber& f = self->fibers_[self->current_];
-    (*self->job_)(f.job);
-    f.done = true;
-    swapcontext(&f.ctx, &self->main_ctx_);
+    alfa_ctx_switch(&f.sp, self->main_sp_);     // never resumed: a finished fiber is prepared afresh for its next job
+    abort();
+}
+
+// initial frame: six zeroed callee-saved registers, then the entry point as the return address of alfa_ctx_switch; the
+// entry function starts with the stack 8 bytes off 16-byte alignment, as after a call
+void HotSched::prepare(Fiber& f) {
+    uintptr_t top = ((uintptr_t)f.stack + stack_bytes_) & ~(uintptr_t)15;
+    void** p = (void**)(top - 64);
+    for (int k = 0; k < 6; ++k) p[k] = nullptr;
+    p[6] = (void*)&HotSched::fiber_entry;
+    p[7] = nullptr;                              // fake return address of the entry function
+    f.sp = (void*)p;
 }
 
 void HotSched::wait() {
     Fiber& f = fibers_[current_];
-    swapcontext(&f.ctx, &main_ctx_);
+    alfa_ctx_switch(&f.sp, main_sp_);
 }
 
 static void die(const HotOps& ops, const char* what, int rc) {
@@ -129,17 +176,13 @@ void HotSched::run(int n, int max_fibers, const std::function<void(int)>& job) {
         if (f.stack == (char*)MAP_FAILED) throw std::runtime_error("mmap of a fiber stack failed");
         fibers_.push_back(f);
     }
+    tl_sched = this;
     int next = 0, live = 0;
     auto start = [&](int fi) {
         Fiber& f = fibers_[fi];
         f.done = false;
         f.job = next++;
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = stack_bytes_;
-        f.ctx.uc_link = nullptr;
-        uintptr_t p = (uintptr_t)this;
-        makecontext(&f.ctx, (void (*)())trampoline, 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
+        prepare(f);
         live++;
     };
     for (int fi = 0; fi < nf; ++fi) start(fi);
@@ -153,7 +196,7 @@ void HotSched::run(int n, int max_fibers, const std::function<void(int)>& job) {
             }
             for (;;) {
                 current_ = fi;
-                swapcontext(&main_ctx_, &f.ctx);
+                alfa_ctx_switch(&main_sp_, f.sp);
                 if (!f.done) break;      // parked in wait()
                 live--;
                 if (next >= n) break;

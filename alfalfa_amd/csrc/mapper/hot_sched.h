@@ -3,13 +3,11 @@
 //
 // The reference maps one read per kt_for work item and calls the hot path synchronously
 // (src/main.cpp:87-104,126).  A GPU needs >=10^4 independent calls in flight, so every read is mapped
-// inside its own stackful fiber (ucontext): a hot-path call records a request and yields; when all
+// inside its own stackful fiber: a hot-path call records a request and yields; when all
 // fibers of a worker thread are parked the scheduler issues ONE batch call per request kind through the
 // C ABI (include/alfa_hot.h), scatters the results and resumes the fibers.  The mapper code therefore
 // keeps the reference's call structure (and its data-dependent control flow) unchanged.
 #pragma once
-#include <ucontext.h>
-
 #include <cstdint>
 #include <cstdio>
 #include <functional>
@@ -66,14 +64,17 @@ class HotSched {
     void set_task_log(const std::string& prefix);
 
    private:
-    struct Fiber { ucontext_t ctx; char* stack = nullptr; bool done = true; int job = -1; };
-    static void trampoline(unsigned lo, unsigned hi);
+    // Fibers switch with a few instructions (callee-saved registers + stack pointer, x86-64 SysV); ucontext's swapcontext
+    // costs a signal-mask system call per switch, ~14 of them per read.
+    struct Fiber { void* sp = nullptr; char* stack = nullptr; bool done = true; int job = -1; };
+    static void fiber_entry();
+    void prepare(Fiber& f);
     void flush();
     HotOps ops_;
     alfa_dp_params prm_;
     size_t stack_bytes_;
     std::vector<Fiber> fibers_;
-    ucontext_t main_ctx_;
+    void* main_sp_ = nullptr;
     int current_ = -1;
     const std::function<void(int)>* job_ = nullptr;
     std::vector<SeedReq> seed_;
