@@ -78,7 +78,7 @@ def simulate_batch(rng, ref, n, rlen, err):
 TASK_DTYPE = np.dtype([("query", "<u8"), ("target", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("h0", "<i4")])
 
 
-def mapper_dp_tasks(workdir, index_prefix, reads, threads=8):
+def mapper_dp_tasks(workdir, index_prefix, reads, threads=8, device=0):
     """The DP task stream the staged host mapper really issues for `reads`: run the product command line tool
     (alfalfa_amd align, HIP hot path) once with ALFA_TASK_LOG set and load every ksw_extend / ksw_nw / ksw_global
     task it submitted.  Returns {kind: (ctypes DpTask array, keepalive)} for kind in extend/nw/global."""
@@ -94,7 +94,8 @@ def mapper_dp_tasks(workdir, index_prefix, reads, threads=8):
         os.remove(old)
     exe = os.path.join(ROOT, "alfalfa_amd", "alfalfa_amd")
     env = dict(os.environ, ALFA_TASK_LOG=prefix)
-    subprocess.run([exe, "align", "-i", index_prefix, "-0", fq, "-o", os.path.join(workdir, "step.sam"), "-t", str(threads)],
+    subprocess.run([exe, "align", "-i", index_prefix, "-0", fq, "-o", os.path.join(workdir, "step.sam"), "-t", str(threads),
+                    "--device", str(device)],
                    check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     hdrs, seqs = [], []
     for hf in sorted(glob.glob(prefix + ".*.hdr")):
@@ -219,7 +220,7 @@ def main():
         fw, rc, pos, strand = simulate_batch(rng, ref, args.batch, args.read_len, args.err)
         queries = ffi.make_seed_queries(fw + rc, min_len, 10000, sparse_q)
         plan = ffi.SeedPlan(didx, ffi.SEED_SMAM, queries)
-        tk = mapper_dp_tasks(workdir, index_prefix, fw, threads=8)
+        tk = mapper_dp_tasks(workdir, index_prefix, fw, threads=8, device=dev)
         (te, ke), (tn, kn), (tg, kg) = tk["extend"], tk["nw"], tk["global"]
         b_ext = ffi.DpBatch(ffi.DP_EXTEND, P, te, dev)
         b_nw = ffi.DpBatch(ffi.DP_NW, P, tn, dev)
