@@ -1,0 +1,51 @@
+// compat_main.cpp -- exercises include/alfa_compat.hpp (the reference's call signatures over libalfa_hot) and prints what
+// the calls return; tests/test_gpu_compat.py compares the text with the oracle's answers for the same inputs.
+// usage: _compat <ref.fa> <K> <reads.txt>   (one read per line; every call is a batch of one)
+#include <cstdio>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../include/alfa_compat.hpp"
+#include "../include/alfa_index.h"
+
+int main(int argc, char** argv) {
+    if (argc < 4) return 2;
+    alfa_host_index* h = nullptr;
+    if (alfa_host_index_build_fasta(argv[1], atoi(argv[2]), 0, 1, 1, &h)) { fprintf(stderr, "%s\n", alfa_last_error()); return 1; }
+    alfa_compat::sparseSA sa(alfa_host_index_view(h));
+    int8_t mat[25];
+    for (int i = 0, k = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) mat[k++] = (i == 4 || j == 4) ? -1 : (i == j ? 1 : -4);
+    std::ifstream in(argv[3]);
+    std::string line;
+    std::vector<std::string> reads;
+    while (std::getline(in, line)) reads.push_back(line);
+    for (size_t r = 0; r < reads.size(); ++r) {
+        std::vector<alfa_compat::match_t> m;
+        m.push_back(alfa_compat::match_t(-7, -7, -7));        // the calls append: this sentinel must survive
+        sa.SMAM(reads[r], m, 20, 1000, 1);
+        sa.MEM(reads[r], m, 25, 1000, 1);
+        sa.SMEM(reads[r], m, 25, 1000, 1, 10);
+        printf("R %zu %zu", r, m.size());
+        for (auto& x : m) printf(" %ld,%d,%d", x.ref, x.query, x.len);
+        printf("\n");
+    }
+    // DP: each read against the next one
+    auto nt4 = [](const std::string& s) { std::vector<uint8_t> v; for (char c : s) v.push_back(c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : c == 't' ? 3 : 4); return v; };
+    for (size_t r = 0; r + 1 < reads.size(); ++r) {
+        std::vector<uint8_t> q = nt4(reads[r]), t = nt4(reads[r + 1]);
+        if (q.empty() || t.empty()) continue;
+        int qle, tle, gtle, gscore, max_off, nc = 0;
+        uint32_t* cig = nullptr;
+        const int w = 30 + (int)(q.size() > t.size() ? q.size() - t.size() : t.size() - q.size());
+        int se = alfa_compat::ksw_extend((int)q.size(), q.data(), (int)t.size(), t.data(), 5, mat, 6, 1, w, 100, 17, &qle, &tle, &gtle, &gscore, &max_off);
+        int sn = alfa_compat::ksw_nw((int)q.size(), q.data(), (int)t.size(), t.data(), 5, mat, 6, 1, w);
+        int sg = alfa_compat::ksw_global((int)q.size(), q.data(), (int)t.size(), t.data(), 5, mat, 6, 1, w, &nc, &cig);
+        printf("D %zu %d %d %d %d %d %d %d %d %d", r, se, qle, tle, gtle, gscore, max_off, sn, sg, nc);
+        for (int k = 0; k < nc; ++k) printf(" %u", cig[k]);
+        printf("\n");
+        free(cig);
+    }
+    alfa_host_index_free(h);
+    return 0;
+}

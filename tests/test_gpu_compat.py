@@ -1,0 +1,58 @@
+"""include/alfa_compat.hpp: the reference's own call signatures (sparseSA::SMAM/MEM/SMEM, ksw_extend/ksw_nw/ksw_global) over
+libalfa_hot, one call at a time, against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from alfalfa_amd import ffi
+import oracle_ffi as O
+import golden_util as G
+import seqgen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_signatures_batch_of_one(gpu):
+    exe = os.path.join(ROOT, "tests", "_compat")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    d = G.tmpdir()
+    fa = G.input_path("reference.fasta")
+    hidx = ffi.HostIndex.build_fasta(fa, K=3)
+    ref = bytes(ffi.view_arrays(hidx.view)["S"][:40000])
+    rng = np.random.default_rng(21)
+    reads = seqgen.sim_reads(rng, ref, 12, 60, 200, 0.04)
+    reads[3] = reads[2][:80]                      # a pair that aligns well
+    rp = os.path.join(d, "compat_reads.txt")
+    open(rp, "w").write("".join(r.decode() + "\n" for r in reads))
+    p = subprocess.run([exe, fa, "3", rp], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-1000:]
+    lines = p.stdout.decode().split("\n")
+    P = ffi.default_params()
+    nt4 = np.full(256, 4, np.uint8)
+    for i, c in enumerate(b"acgt"):
+        nt4[c] = i
+    for ln in lines:
+        f = ln.split()
+        if not f:
+            continue
+        r = int(f[1])
+        if f[0] == "R":
+            exp = [(-7, -7, -7)]
+            for mt, ml, ms in ((ffi.SEED_SMAM, 20, 0), (ffi.SEED_MEM, 25, 0), (ffi.SEED_SMEM, 25, 10)):
+                m, off = O.orc_seed_batch(hidx.view, mt, ffi.make_seed_queries([reads[r]], ml, 1000, 1, ms))
+                exp += [(int(x["ref"]), int(x["query"]), int(x["len"])) for x in m]
+            got = [tuple(int(v) for v in t.split(",")) for t in f[3:]]
+            assert int(f[2]) == len(exp) and got == exp, r
+        else:
+            q, t = nt4[np.frombuffer(reads[r], np.uint8)], nt4[np.frombuffer(reads[r + 1], np.uint8)]
+            w = 30 + abs(len(q) - len(t))
+            tk, keep = ffi.make_dp_tasks([(q, t)], w, 17)
+            e = O.orc_ksw_extend_batch(P, tk)[0]
+            tk0, keep0 = ffi.make_dp_tasks([(q, t)], w, 0)
+            sn = int(O.orc_ksw_nw_batch(P, tk0)[0])
+            sg, cig, nc, off = O.orc_ksw_global_batch(P, tk0)
+            exp = [int(x) for x in e] + [sn, int(sg[0]), int(nc[0])] + [int(c) for c in cig[:nc[0]]]
+            assert [int(v) for v in f[2:]] == exp, r
