@@ -5,23 +5,27 @@
 //   ksw_nw      :544-591   banded global score
 //   ksw_global  :468-542   banded global + direction bytes + backtrack -> BAM CIGAR
 //
-// Design (one task per wavefront, no LDS, no barriers, no MFMA -- integer max-plus):
-//   * Band-diagonal register layout.  Lane l owns C consecutive band diagonals
+// Design (no MFMA -- integer max-plus; registers only, no barriers in the row loop):
+//   * Band-diagonal register layout.  A lane owns C consecutive band diagonals
 //     d = l*C+c, d = j - i + w.  H(i-1,j-1) -> H(i,j) stays in the same register,
 //     E(i,j) arrives from diagonal d+1 (one cross-lane shift per row) and the
 //     horizontal F recurrence, the only true intra-row dependency, becomes an exact
-//     max-plus prefix scan across the wave:
+//     max-plus prefix scan across the lanes:
 //        F(d+1) = max(F(d) - gape, B(d)),  B(d) = A(d) - gapoe  (A = max(Hdiag+s, E))
-//     which is lane-local over C slots plus one 64-lane exclusive max-scan of
+//     which is lane-local over C slots plus one exclusive max-scan of
 //     G(l) = L(l) + l*C*gape.  Integer max/plus is associative, so the scan is
 //     bit-identical to the reference's left-to-right loop.
 //   * Row maxima (m, mj), the Z-drop test, the gscore cell and the band-shrink scans
-//     of ksw_extend are wave reductions over the same registers.
+//     of ksw_extend are reductions over the same registers.
+//   * Two widths: ksw_group_kernel gives a task one DPP row (16 lanes, bands of up to 16/32/64
+//     diagonals, four tasks per wavefront: the short-read case); ksw_wave_kernel gives it the whole
+//     wavefront (bands of up to 128/256 diagonals).  All cross-lane steps are DPP moves.
 //   * ksw_global packs one direction byte per cell (reference encoding, ksw.c:506-519)
-//     into coalesced per-row stores to HBM; a second tiny kernel walks them back.
-//   * Tasks whose band does not fit 64*C diagonals (C<=4), and degenerate 0-length
-//     tasks, run in a scalar lane-per-task kernel that follows the reference loop
-//     literally (the rare tail; never the throughput path).
+//     into coalesced per-row stores to HBM; a second kernel walks them back (from LDS copies
+//     when the matrix is small).
+//   * Tasks whose band does not fit 256 diagonals, and degenerate 0-length tasks, run in a
+//     lane-per-task kernel that follows the reference loop literally (the rare tail).
+//   * The kernel bins of a batch run as independent chains on side streams (launch_all).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>

@@ -7,15 +7,17 @@
 //
 // Work decomposition: the reference walks, for each phase k<K, the prefixes k, k+q*K, k+2q*K ...
 // of a read and (without suffix links, the default index) restarts from the root for every prefix,
-// so every (read, prefix) pair is an independent query.  One workgroup owns one read (one strand);
-// the read is staged once into LDS; each lane owns one prefix query at a time:
-//   10-mer table jump (8 B) -> child-table descent (CHILD/LCP/SA probes) -> edge walk against S
-// Results are produced deterministically in the reference's emission order without a global sort:
-//   kernel A  traverse + count the matches every query will emit, block-level exclusive scan gives
-//             the offset inside the read, emitting queries append a 24-byte record to a work list
+// so every (read, prefix) pair is an independent query.  Results are produced deterministically in the
+// reference's emission order without a global sort:
+//   kernel A  count the matches every query will emit and give each emitting query its offset inside
+//             the read; emitting queries append a 24-byte record to a (segmented) work list
 //   scan      exclusive sum of the per-read totals
 //   kernel B  one lane per work-list record re-enumerates its SA interval, left-extends
 //             (find_LmaximalStrict) and writes match_t records at base[read] + offset
+// Kernel A exists in two forms: smam_count_kernel (the throughput path: persistent workgroups, the 10-mer presence
+// bitmap in LDS, three queued stages filter / table / evaluate -- see the comment above it) and
+// smam_count_simple_kernel (one workgroup per read, every lane walks its query to the end; indexes without a
+// child table or without the 10-mer table).
 //
 // The other seed types use the same count / scan / emit structure:
 //   MEM   (sparseSA::MEM  :1116-1119 -> findMEM :993-1060 -> collectAllMEMs :873-899), CLI "--seed MEM"
@@ -23,7 +25,8 @@
 //         (tuples ordered by end position, beginLong/smemCount tables, the curMinPos sweep) runs on one lane of the
 //         read's workgroup between the parallel traversal and the parallel counting stages.
 // Indexes without a child table (--no-child) take the binary-search descent (traverse :701-728, top_down_faster :614-666)
-// for SMAM and MEM.  Suffix-link indexes and SMEMP (unreachable from the reference's command line) have no kernel.
+// for SMAM and MEM.  On suffix-link indexes (--suflink) the prefixes of a phase form a chain (smam_suflink_kernel: lane =
+// (read, phase)).  SMEMP (unreachable from the reference's command line) and MEM on a suffix-link index have no kernel.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
