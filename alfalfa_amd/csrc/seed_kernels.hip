@@ -26,7 +26,7 @@
 //         read's workgroup between the parallel traversal and the parallel counting stages.
 // Indexes without a child table (--no-child) take the binary-search descent (traverse :701-728, top_down_faster :614-666)
 // for SMAM and MEM.  On suffix-link indexes (--suflink) the prefixes of a phase form a chain (smam_suflink_kernel: lane =
-// (read, phase)).  SMEMP (unreachable from the reference's command line) and MEM on a suffix-link index have no kernel.
+// (read, phase)).  SMEMP (unreachable from the reference's command line) has no kernel.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -1101,6 +1101,7 @@ __device__ bool d_suffixlink(const DIdx& X, IvalD& m) {
     const int64_t is = (int64_t)X.SA[m.start] / X.K + 1, ie = (int64_t)X.SA[m.end] / X.K + 1;
     if (is >= X.n || ie >= X.n) return false;          // (the reference reads one past its ISA here)
     int start = X.ISA[is], end = X.ISA[ie];
+    m.start = start; m.end = end;                      // kept (unexpanded) when the expansion below gives up, as in the reference
     const int64_t thresh = 2 * (int64_t)m.depth * X.logN;
     int64_t exp = 0;
     while (start > 0 && d_lcp(X, start) >= m.depth) { if (++exp >= thresh) return false; --start; }
@@ -1112,7 +1113,7 @@ __device__ bool d_suffixlink(const DIdx& X, IvalD& m) {
 // With suffix links the prefixes of one phase k form a chain (findSMAM :1063-1114: the interval reached for one prefix is
 // carried, through sparseQ suffix links, into the next), so the unit of parallel work is (read, phase): lane k of the read's
 // workgroup walks phase k.  Pass 1 (EMIT = false) counts per phase; pass 2 re-walks and writes at the scanned offsets.
-template <bool EMIT>
+template <int TYPE, bool EMIT>
 __global__ __launch_bounds__(SEED_BLOCK) void smam_suflink_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
                                                                  int64_t* __restrict__ read_total, int32_t* __restrict__ phase_cnt,
                                                                  const int64_t* __restrict__ read_base, alfa_match* __restrict__ out,
@@ -1153,23 +1154,47 @@ __global__ __launch_bounds__(SEED_BLOCK) void smam_suflink_kernel(DIdx X, const 
             alfa_match* o = EMIT ? out + read_base[r] + my_off : nullptr;
             IvalD xmi = {0, X.n - 1, 0};
             int prefix = k;
-            while (prefix <= Q.plen - min_lenK) {
-                traverse_any(X, P, prefix, xmi, Q.plen);
-                if (xmi.depth <= 1) { xmi = {0, X.n - 1, 0}; prefix += step; continue; }
-                if (xmi.depth >= min_lenK && (xmi.end - xmi.start + 1) <= maxCount) {
-                    for (int i = xmi.start; i <= xmi.end; ++i) {
-                        int64_t mr; int mq, ml;
-                        if (lmax_strict(X, P, prefix, (int64_t)X.SA[i], xmi.depth, minMin_len, step, mr, mq, ml)) {
-                            if (EMIT) { alfa_match m; m.ref = mr; m.query = mq; m.len = ml; o[cnt] = m; }
-                            ++cnt;
+            if (TYPE == ALFA_SEED_SMAM) {
+                while (prefix <= Q.plen - min_lenK) {
+                    traverse_any(X, P, prefix, xmi, Q.plen);
+                    if (xmi.depth <= 1) { xmi = {0, X.n - 1, 0}; prefix += step; continue; }
+                    if (xmi.depth >= min_lenK && (xmi.end - xmi.start + 1) <= maxCount) {
+                        for (int i = xmi.start; i <= xmi.end; ++i) {
+                            int64_t mr; int mq, ml;
+                            if (lmax_strict(X, P, prefix, (int64_t)X.SA[i], xmi.depth, minMin_len, step, mr, mq, ml)) {
+                                if (EMIT) { alfa_match m; m.ref = mr; m.query = mq; m.len = ml; o[cnt] = m; }
+                                ++cnt;
+                            }
                         }
                     }
+                    prefix += step;
+                    int i = 0;
+                    bool ok = true;
+                    while (i < Q.sparse_q && (ok = d_suffixlink(X, xmi))) ++i;
+                    if (!ok) xmi = {0, X.n - 1, 0};
                 }
-                prefix += step;
-                int i = 0;
-                bool ok = true;
-                while (i < Q.sparse_q && (ok = d_suffixlink(X, xmi))) ++i;
-                if (!ok) xmi = {0, X.n - 1, 0};
+            } else {
+                // findMEM :993-1060 with suffix links: mli (matched to min_lenK) and xmi (matched to the end) are both carried
+                IvalD mli = {0, X.n - 1, 0};
+                while (prefix <= Q.plen - min_lenK) {
+                    traverse_any(X, P, prefix, mli, min_lenK);
+                    if (mli.depth > xmi.depth) xmi = mli;
+                    if (mli.depth <= 1) { mli = {0, X.n - 1, 0}; xmi = mli; prefix += step; continue; }
+                    bool ok = true;
+                    int i = 0;
+                    if (mli.depth >= min_lenK) {
+                        traverse_any(X, P, prefix, xmi, Q.plen);
+                        cnt += collect_mem<EMIT>(X, P, prefix, mli, xmi, Q.min_len, step, EMIT ? o + cnt : nullptr);
+                        prefix += step;
+                        while (i < Q.sparse_q && (ok = d_suffixlink(X, mli))) { (void)d_suffixlink(X, xmi); ++i; }
+                        if (!ok) { mli = {0, X.n - 1, 0}; xmi = mli; }
+                    } else {
+                        prefix += step;
+                        while (i < Q.sparse_q && (ok = d_suffixlink(X, mli))) ++i;
+                        if (!ok) { mli = {0, X.n - 1, 0}; xmi = mli; }
+                        else xmi = mli;
+                    }
+                }
             }
         }
         if (!EMIT) {
@@ -1311,8 +1336,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
         return alfa::fail(ALFA_ENOTSUP, "seed type has no HIP kernel (SMAM, MEM and SMEM do; SMEMP is unreachable from the reference's CLI)");
     if (!ix->has_child && mem_type == ALFA_SEED_SMEM)
         return alfa::fail(ALFA_ENOTSUP, "SMEM needs an index with a child table (the reference calls traverse_faster unconditionally)");
-    if (ix->has_suflink && mem_type == ALFA_SEED_MEM)
-        return alfa::fail(ALFA_ENOTSUP, "MEM on a suffix-link (--suflink) index has no HIP kernel (SMAM and SMEM do)");
+
     pl->ix = ix; pl->nq = nq; pl->launched = false; pl->mem_type = mem_type;
     pl->work_rec = mem_type == ALFA_SEED_SMAM ? sizeof(WorkRec) : sizeof(WorkRec2);
     if (!pl->ev0) { ALFA_HIP(hipEventCreate(&pl->ev0)); ALFA_HIP(hipEventCreate(&pl->ev1)); }
@@ -1378,7 +1402,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
         if (!pl->lds_tab && (rc = pl->d_scr.reserve(4 * (size_t)scr_ints + 64))) return rc;
     }
     static const bool force_simple = getenv("ALFA_SEED_SIMPLE") != nullptr;   // A/B switch for profiling
-    pl->suflink = mem_type == ALFA_SEED_SMAM && ix->has_suflink;
+    pl->suflink = (mem_type == ALFA_SEED_SMAM || mem_type == ALFA_SEED_MEM) && ix->has_suflink;
     pl->persistent = mem_type == ALFA_SEED_SMAM && ix->has_child && ix->has_kmer && !force_simple && magic_ok && !pl->suflink;
     if (pl->suflink && (rc = pl->d_scr.reserve(4 * (size_t)nq * (size_t)ix->K + 64))) return rc;
     pl->nseg = 1;
@@ -1427,8 +1451,12 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
     ALFA_HIP(hipMemsetAsync(d_tot, 0, 8 * ((size_t)nq + 1), st));       // the persistent kernel accumulates per-read totals
     ALFA_HIP(hipEventRecord(pl->ev0, st));
     if (pl->suflink) {
-        hipLaunchKernelGGL(smam_suflink_kernel<false>, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot, pl->d_scr.as<int32_t>(),
-                           (const int64_t*)nullptr, (alfa_match*)nullptr, (int64_t)0, nq, lds_p);
+        if (pl->mem_type == ALFA_SEED_SMAM)
+            hipLaunchKernelGGL((smam_suflink_kernel<ALFA_SEED_SMAM, false>), dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot,
+                               pl->d_scr.as<int32_t>(), (const int64_t*)nullptr, (alfa_match*)nullptr, (int64_t)0, nq, lds_p);
+        else
+            hipLaunchKernelGGL((smam_suflink_kernel<ALFA_SEED_MEM, false>), dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot,
+                               pl->d_scr.as<int32_t>(), (const int64_t*)nullptr, (alfa_match*)nullptr, (int64_t)0, nq, lds_p);
     } else if (pl->persistent) {
         // one workgroup per CU, the 10-mer bitmap + one read slice per wave in LDS
         const size_t lds = (size_t)KBIT_BYTES + (size_t)PWAVES * (2 * pl->stride + WQ_BYTES);      // read bytes + 2-bit codes + survivor queue per wave
@@ -1451,9 +1479,12 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
     size_t tb = pl->tmp_bytes;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_tmp.p, tb, d_tot, d_base, nq + 1, st));
     const dim3 eg((pl->seg_cap + 127) / 128, pl->nseg), eb(128);
-    if (pl->suflink)
-        hipLaunchKernelGGL(smam_suflink_kernel<true>, dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot, pl->d_scr.as<int32_t>(),
-                           (const int64_t*)d_base, pl->d_out.as<alfa_match>(), pl->out_cap, nq, lds_p);
+    if (pl->suflink && pl->mem_type == ALFA_SEED_SMAM)
+        hipLaunchKernelGGL((smam_suflink_kernel<ALFA_SEED_SMAM, true>), dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot,
+                           pl->d_scr.as<int32_t>(), (const int64_t*)d_base, pl->d_out.as<alfa_match>(), pl->out_cap, nq, lds_p);
+    else if (pl->suflink)
+        hipLaunchKernelGGL((smam_suflink_kernel<ALFA_SEED_MEM, true>), dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot,
+                           pl->d_scr.as<int32_t>(), (const int64_t*)d_base, pl->d_out.as<alfa_match>(), pl->out_cap, nq, lds_p);
     else if (pl->mem_type == ALFA_SEED_SMAM)
         hipLaunchKernelGGL(smam_emit_kernel, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec>(), d_cnt, pl->seg_cap,
                            pl->d_out.as<alfa_match>(), pl->out_cap);

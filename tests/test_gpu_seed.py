@@ -147,15 +147,13 @@ def test_smam_suffix_link_index(gpu, K):
     _check(hidx, didx, reads, max(20, K + 10), 100000, 1)
     _check(hidx, didx, reads, 25, 3, 1)
     assert _check(hidx, didx, reads, ml, 10000, sq, ffi.SEED_SMEM, 10) > 100      # SMEM does not use the links
+    assert _check(hidx, didx, reads, ml, 10000, sq, ffi.SEED_MEM) > 200           # findMEM carries mli and xmi through the links
+    _check(hidx, didx, reads, max(20, K + 10), 100000, 1, ffi.SEED_MEM)
 
 
 def test_unsupported_types_fail_loudly(gpu):
     rng = np.random.default_rng(5)
     ref = seqgen.rand_ref(rng, 20000)
-    hidx = ffi.HostIndex.build_mem(["x"], [ref], K=3, suflink=True)
-    didx = ffi.DeviceIndex(hidx, gpu)
-    with pytest.raises(ffi.AlfaError):
-        didx.seed_batch(ffi.SEED_MEM, ffi.make_seed_queries([ref[:100]], 40, 100, 1))
     hidx2 = ffi.HostIndex.build_mem(["x"], [ref], K=3)
     didx2 = ffi.DeviceIndex(hidx2, gpu)
     with pytest.raises(ffi.AlfaError):
