@@ -618,6 +618,60 @@ __global__ void ksw_backtrack_kernel(const DevTask* __restrict__ tasks, int ntas
     ncig[T.orig] = n;
 }
 
+// Same walk for long tasks, one wavefront per task: the direction matrix is pulled through LDS in tiles of TILE_ROWS rows with
+// coalesced 16-byte loads by all lanes, and lane 0 walks inside the tile -- one HBM round trip per tile instead of one per
+// step (a 5 kbp x 5 kbp alignment is ~10^4 dependent steps: ~10 ms walking HBM, the critical path of a long-read batch).
+constexpr int TILE_ROWS = 64;
+constexpr int LONG_TLEN = 512;        // from this many rows on, the tiled walk beats one lane per task walking HBM
+__global__ __launch_bounds__(64) void ksw_backtrack_tile_kernel(const DevTask* __restrict__ tasks, int ntask, const uint8_t* __restrict__ zbuf,
+                                                               uint32_t* __restrict__ cig, int32_t* __restrict__ ncig, int ROWB) {
+    __shared__ uint4 tile[TILE_ROWS * 256 / 16];                 // ROWB <= 256
+    const int t = blockIdx.x;
+    if (t >= ntask) return;
+    const int lane = threadIdx.x;
+    const DevTask T = tasks[t];
+    const int qlen = T.qlen, tlen = T.tlen, w = T.w;
+    if (tlen > qlen + w) { if (lane == 0) ncig[T.orig] = -1; return; }   // reference indexes outside the matrix: unspecified
+    uint32_t* slot = cig + T.cigoff;
+    int pos = T.cigcap, n = 0;
+    uint32_t cur_op = 0xffffffffu, cur_len = 0;
+    auto push = [&](uint32_t op, uint32_t len) {
+        if (op == cur_op) { cur_len += len; return; }
+        if (cur_op != 0xffffffffu) { slot[--pos] = cur_len << 4 | cur_op; ++n; }
+        cur_op = op; cur_len = len;
+    };
+    int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+    int which = 0;
+    const uint8_t* z = zbuf + T.zoff;                            // 16-byte aligned, rows of ROWB (a multiple of 16) bytes
+    const int v_per_row = ROWB >> 4;
+    while (i >= 0 && k >= 0) {                                   // i, k are uniform: lane 0's values are broadcast after each tile
+        const int lo = i - TILE_ROWS + 1 > 0 ? i - TILE_ROWS + 1 : 0;
+        const int nv = (i - lo + 1) * v_per_row;
+        const uint4* src = (const uint4*)(z + (int64_t)lo * ROWB);
+        for (int x = lane; x < nv; x += 64) tile[x] = src[x];
+        __syncthreads();
+        if (lane == 0) {
+            const uint8_t* zt = (const uint8_t*)tile;
+            while (i >= lo && k >= 0) {
+                const uint32_t zv = zt[(i - lo) * ROWB + (k - i + w)];
+                which = (zv >> (which << 1)) & 3;
+                if (which == 0) { push(0, 1); --i; --k; }
+                else if (which == 1) { push(2, 1); --i; }
+                else { push(1, 1); --k; }
+            }
+        }
+        i = __shfl(i, 0, 64);
+        k = __shfl(k, 0, 64);
+        __syncthreads();
+    }
+    if (lane == 0) {
+        if (i >= 0) push(2, (uint32_t)(i + 1));
+        if (k >= 0) push(1, (uint32_t)(k + 1));
+        if (cur_op != 0xffffffffu) { slot[--pos] = cur_len << 4 | cur_op; ++n; }
+        ncig[T.orig] = n;
+    }
+}
+
 // Same walk for small tasks (direction matrix of at most ZC bytes): every lane first copies its task's matrix into its own
 // LDS slice with independent 16-byte loads, then walks it there -- ~50 dependent LDS reads instead of ~50 dependent HBM reads.
 constexpr int ZC = 512;        // 64 tasks per workgroup
@@ -841,6 +895,7 @@ struct alfa_dp_batch {
     std::vector<int> dense_of;      // device order -> caller index
     int bin_cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // lane kernel (qlen <= 30, 62, 126), group kernel C=1,2,4, wave kernel C=2,4, generic
     int nbig[3] = {0, 0, 0};        // group bins: tasks whose direction matrix exceeds ZC bytes (a prefix: sorted by tlen)
+    int nlong[3] = {0, 0, 0};       // ... of which targets of at least LONG_TLEN rows (a shorter prefix): tiled wave-per-task backtrack
     int64_t cig_words = 0, cells = 0, zbytes = 0, eh_items = 0;
     size_t seq_bytes = 0, out_bytes = 0;
     alfa::DevBuf d_seq, d_tasks, d_out, d_z, d_cig, d_eh;
@@ -960,8 +1015,12 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
                     hipLaunchKernelGGL((ksw_backtrack_lds_kernel<ZC, 64>), dim3((n - nbig + 63) / 64), dim3(64), 0, s3, d_t + o + nbig, n - nbig,
                                        d_z, d_cig, d_ncig, rowb);
                 }
-                if (nbig > 0)
-                    hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((nbig + 63) / 64), dim3(64), 0, s2, d_t + o, nbig, d_z, d_cig, d_ncig, rowb);
+                const int nlong = std::min(b->nlong[g], nbig);
+                if (nlong > 0)
+                    hipLaunchKernelGGL(ksw_backtrack_tile_kernel, dim3(nlong), dim3(64), 0, s2, d_t + o, nlong, d_z, d_cig, d_ncig, rowb);
+                if (nbig > nlong)
+                    hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((nbig - nlong + 63) / 64), dim3(64), 0, s2, d_t + o + nlong, nbig - nlong, d_z, d_cig,
+                                       d_ncig, rowb);
             }
         }
         o += n;
@@ -971,14 +1030,14 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
         hipStream_t s2 = side(3);
         launch_wave<MODE, 2>(s2, d_t + o, bc[6], d_seq, d_prm, d_out, d_z);
         if (MODE == MODE_GLOBAL)
-            hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[6] + 63) / 64), dim3(64), 0, s2, d_t + o, bc[6], d_z, d_cig, d_ncig, 64 * 2);
+            hipLaunchKernelGGL(ksw_backtrack_tile_kernel, dim3(bc[6]), dim3(64), 0, s2, d_t + o, bc[6], d_z, d_cig, d_ncig, 64 * 2);
     }
     o += bc[6];
     if (bc[7]) {
         hipStream_t s2 = side(4);
         launch_wave<MODE, 4>(s2, d_t + o, bc[7], d_seq, d_prm, d_out, d_z);
         if (MODE == MODE_GLOBAL)
-            hipLaunchKernelGGL(ksw_backtrack_kernel, dim3((bc[7] + 63) / 64), dim3(64), 0, s2, d_t + o, bc[7], d_z, d_cig, d_ncig, 64 * 4);
+            hipLaunchKernelGGL(ksw_backtrack_tile_kernel, dim3(bc[7]), dim3(64), 0, s2, d_t + o, bc[7], d_z, d_cig, d_ncig, 64 * 4);
     }
     o += bc[7];
     bool any = false;
@@ -998,7 +1057,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
     b->mode = mode; b->n = n; b->device = cx->device; b->launched = false; b->kernel_ms = 0;
     b->cig_words = b->cells = b->zbytes = b->eh_items = 0;
     for (int k = 0; k < 9; ++k) b->bin_cnt[k] = 0;
-    for (int k = 0; k < 3; ++k) b->nbig[k] = 0;
+    for (int k = 0; k < 3; ++k) b->nbig[k] = b->nlong[k] = 0;
     b->ht.resize((size_t)n);
     b->dense_of.resize((size_t)n);
     if (!b->ev0) { ALFA_HIP(hipEventCreate(&b->ev0)); ALFA_HIP(hipEventCreate(&b->ev1)); }
@@ -1021,6 +1080,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         bins[i] = bin;
         b->bin_cnt[bin]++;
         if (bin >= 3 && bin <= 5 && (int64_t)x.tlen * (GL << (bin - 3)) > ZC) b->nbig[bin - 3]++;
+        if (bin >= 3 && bin <= 5 && x.tlen >= LONG_TLEN) b->nlong[bin - 3]++;
         seq_bytes += (size_t)x.qlen + (size_t)x.tlen;
     }
     // order: by bin; inside a bin the most work first, so that the 64 tasks of a lane-kernel wave (and co-resident waves of the
