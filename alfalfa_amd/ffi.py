@@ -56,6 +56,14 @@ class ExtendResult(C.Structure):
 EXTEND_DTYPE = np.dtype([("score", "<i4"), ("qle", "<i4"), ("tle", "<i4"), ("gtle", "<i4"), ("gscore", "<i4"), ("max_off", "<i4")])
 
 
+class AlignTask(C.Structure):       # alfa_align_task
+    _fields_ = [("query", C.c_void_p), ("target", C.c_void_p), ("qlen", C.c_int32), ("tlen", C.c_int32), ("xtra", C.c_int32)]
+
+
+KSWR_DTYPE = np.dtype([(n, "<i4") for n in ("score", "te", "qe", "score2", "te2", "tb", "qb")])   # alfa_kswr = kswr_t
+KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
+
+
 class DpbandTask(C.Structure):      # alfa_dpband_task
     _fields_ = [("ref", C.c_char_p), ("ref_len", C.c_int64), ("query", C.c_char_p), ("query_len", C.c_int64),
                 ("refB", C.c_int64), ("refE", C.c_int64), ("queryB", C.c_int32), ("queryE", C.c_int32),
@@ -313,6 +321,36 @@ def ksw_global_batch(params, tasks):
         check(rc)
         return rc
     return _global_call(fn, params, tasks, lib().alfa_free)
+
+
+def make_align_tasks(pairs, xtra):
+    """pairs: list of (query uint8 ndarray, target uint8 ndarray); xtra: int or per-task list (KSW_X* flags | threshold)."""
+    n = len(pairs)
+    xs = xtra if isinstance(xtra, (list, tuple, np.ndarray)) else [xtra] * n
+    t = (AlignTask * n)()
+    keep = []
+    for i, (q, tg) in enumerate(pairs):
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        tg = np.ascontiguousarray(tg, dtype=np.uint8)
+        keep.append((q, tg))
+        t[i].query = q.ctypes.data
+        t[i].target = tg.ctypes.data
+        t[i].qlen = len(q)
+        t[i].tlen = len(tg)
+        t[i].xtra = int(xs[i])
+    return t, keep
+
+
+def align_call(fn, params, tasks):
+    n = len(tasks)
+    out = np.zeros(n, dtype=KSWR_DTYPE)
+    check(fn(C.byref(params), tasks, n, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def ksw_align_batch(params, tasks):
+    """alfa_ksw_align_batch: params.gapo / gape are used as given (the reference's callers pass negative numbers)."""
+    return align_call(lib().alfa_ksw_align_batch, params, tasks)
 
 
 def make_dpband_tasks(specs):

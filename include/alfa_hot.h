@@ -129,6 +129,27 @@ int  alfa_ksw_nw_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, in
 int  alfa_ksw_global_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, int32_t* score,
                            uint32_t** cigar, int32_t* n_cigar, int64_t* cig_off);
 
+/* --- local alignment (striped Smith-Waterman) ---------------------------- */
+/* replaces: ksw_align(qlen, query, tlen, target, m, mat, gapo, gape, xtra, 0)  src/ksw.h:63 / src/ksw.c:330
+ * (= ksw_qinit :58 + ksw_u8 :106 / ksw_i16 :223, second pass for the start positions), the mate-rescue call of
+ * src/mapper.cpp:1571 and :2196.  `xtra` carries the reference's KSW_X* flags and threshold (src/ksw.h:6-9).
+ * p->gapo / p->gape are used AS GIVEN: the reference's call sites pass alnOptions.openGap / extendGap, which are
+ * negative, and its unsigned saturating arithmetic then never lets a gap pay; that behaviour is reproduced
+ * (results are bit-identical for either sign).  p->zdrop is ignored.  EINVAL: qlen < 0, tlen < 0,
+ * qlen * max(mat) > 32767, or KSW_XSUBO with max(mat) <= 0 (the reference divides by zero). */
+#define ALFA_KSW_XBYTE  0x10000
+#define ALFA_KSW_XSTOP  0x20000
+#define ALFA_KSW_XSUBO  0x40000
+#define ALFA_KSW_XSTART 0x80000
+typedef struct {
+    const uint8_t* query;       /* nt4 codes 0..m-1 */
+    const uint8_t* target;
+    int32_t qlen, tlen;
+    int32_t xtra;
+} alfa_align_task;
+typedef struct { int32_t score, te, qe, score2, te2, tb, qb; } alfa_kswr;   /* = kswr_t, src/ksw.h:14-19 */
+int  alfa_ksw_align_batch(const alfa_dp_params* p, const alfa_align_task* t, int n, alfa_kswr* r);
+
 /* --- dynProg (dp.cpp) ---------------------------------------------------- */
 #define ALFA_DPBAND_STATIC 0   /* dynProg::dpBandStatic src/dp.cpp:648 */
 #define ALFA_DPBAND_FULL   1   /* dynProg::dpBandFull   src/dp.cpp:761 */

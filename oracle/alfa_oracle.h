@@ -51,6 +51,11 @@ int orc_ksw_extend_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, 
 int orc_ksw_nw_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, int32_t* score);
 int orc_ksw_global_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, int32_t* score,
                          uint32_t** cigar, int32_t* n_cigar, int64_t* cig_off);
+/* ksw_align (align_oracle.cpp): the striped SSE2 kernel restated lane by lane */
+void orc_ksw_align(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int m, const int8_t* mat,
+                   int gapo, int gape, int xtra, alfa_kswr* out);
+int orc_ksw_align_batch(const alfa_dp_params* p, const alfa_align_task* t, int n, alfa_kswr* r);
+int64_t orc_cells_align_take(void);   /* query length x rows processed since the last call (this thread) */
 /* dynProg (dp_oracle.cpp).  r[k].ret: 0/1 = the reference's return value, 2 = the reference reads a matrix cell it never
  * wrote (result undefined), 3 = the reference prints "Error in dynamic programming" and exits.  Returns -22 for arguments
  * the reference asserts on or indexes out of bounds with (orc_dp_band_check). */

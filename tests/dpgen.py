@@ -116,3 +116,53 @@ def dpband_cases(rng, n, variant, max_len=200, alphabet=b"acgt"):
 
 
 DPBAND_SCORES = [(1, -4, -6, -1), (2, -2, -2, -2), (1, -1, 0, -1), (0, -2, 0, -2), (3, -5, -8, -3), (1, -3, 0, -2)]
+
+
+# ---------------------------------------------------------------- ksw_align (src/ksw.c:330) cases
+# (match, mismatch, gapo, gape) exactly as handed to ksw_align: the reference's call sites pass NEGATIVE gap numbers
+ALIGN_SCORES = [(1, -4, -6, -1), (1, -4, 6, 1), (2, -3, 5, 2), (1, -1, 0, 1), (1, -2, 0, 0), (5, -4, 10, 1), (2, -2, -2, -2),
+                (1, -4, 1, 6), (3, -1, 2, 0)]
+XBYTE, XSTOP, XSUBO, XSTART = 0x10000, 0x20000, 0x40000, 0x80000
+
+
+def align_cases(seed, n, max_q=300, max_t=700, match=1):
+    """mate-rescue shaped local alignments: a window with zero, one or two (mutated) copies of the query.
+    Returns (pairs, xtras).  The xtra of most cases is the mapper's own (KSW_XSTART | KSW_XBYTE when qlen*match < 250)."""
+    rng = np.random.default_rng(seed)
+    pairs, xs = [], []
+    qchoices = (0, 1, 2, 7, 8, 9, 15, 16, 17, 31, 33, 50, 100, 101, 150, 249, 250, max_q)
+    for _ in range(n):
+        ql = int(rng.choice(qchoices)) if rng.random() < 0.5 else int(rng.integers(0, max_q + 1))
+        q = rng.integers(0, 4, ql).astype(np.uint8)
+        parts = [rng.integers(0, 4, int(rng.integers(0, max_t // 3 + 1))).astype(np.uint8)]
+        copies = int(rng.choice([0, 1, 1, 1, 2]))
+        for _c in range(copies):
+            a, b = sorted(int(x) for x in rng.integers(0, ql + 1, 2)) if rng.random() < 0.3 else (0, ql)
+            parts.append(mutate(rng, q[a:b], float(rng.choice([0, 0.02, 0.05, 0.15]))))
+            parts.append(rng.integers(0, 4, int(rng.integers(0, max_t // 4 + 1))).astype(np.uint8))
+        t = np.concatenate(parts)[:max_t]
+        if rng.random() < 0.03:
+            t = t[:int(rng.integers(0, 3))]
+        if rng.random() < 0.1 and len(q):
+            q[rng.integers(0, len(q))] = 4
+        if rng.random() < 0.1 and len(t):
+            t[rng.integers(0, len(t))] = 4
+        u = rng.random()
+        x = XSTART | (XBYTE if ql * match < 250 else 0)
+        if u < 0.15:
+            x = XSTART | XSUBO | int(rng.integers(0, 60)) | (XBYTE if rng.random() < 0.5 else 0)
+        elif u < 0.25:
+            x = XSTOP | int(rng.integers(1, 80)) | (XSTART if rng.random() < 0.5 else 0) | (XBYTE if rng.random() < 0.5 else 0)
+        elif u < 0.32:
+            x = int(rng.choice([0, XBYTE, XSUBO | 10, XSUBO | XBYTE | 5, XSTART, XSTART | XBYTE]))
+        pairs.append((q, t))
+        xs.append(int(x))
+    return pairs, xs
+
+
+def align_params(sc):
+    """DpParams for one ALIGN_SCORES entry (gap numbers untouched)"""
+    from alfalfa_amd import ffi
+    p = ffi.default_params(match=sc[0], mismatch=sc[1])
+    p.gapo, p.gape = sc[2], sc[3]
+    return p

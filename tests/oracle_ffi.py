@@ -197,6 +197,28 @@ def ref_ksw_global(params, q, t, w):
     return s, cig
 
 
+class _Kswr(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("score", "te", "qe", "score2", "te2", "tb", "qb")]
+
+
+def orc_ksw_align_batch(params, tasks):
+    n = len(tasks)
+    out = np.zeros(n, dtype=ffi.KSWR_DTYPE)
+    oracle().orc_ksw_align_batch(C.byref(params), tasks, n, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def ref_ksw_align(params, q, t, xtra):
+    """the REAL ksw_align (src/ksw.c:330), qry = NULL; gapo/gape passed as params holds them"""
+    L = reflib()
+    L.ksw_align.restype = _Kswr
+    q = np.array(q, dtype=np.uint8)          # copies: the reference reverses its arguments in place
+    t = np.array(t, dtype=np.uint8)
+    r = L.ksw_align(len(q), q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), params.m, _mat_ptr(params),
+                    params.gapo, params.gape, int(xtra), None)
+    return (r.score, r.te, r.qe, r.score2, r.te2, r.tb, r.qb)
+
+
 # ---------------------------------------------------------------- dynProg (dp.cpp)
 def orc_dp_band_batch(variant, scores, tasks):
     L = oracle()

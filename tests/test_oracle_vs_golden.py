@@ -47,3 +47,24 @@ def test_oracle_vs_live_reference_nochild_and_suflink():
 
 def test_oracle_dynprog_vs_reference_goldens():
     assert G.check_dpband(O.orc_dp_band_batch) > 1000
+
+
+def test_oracle_ksw_align_vs_reference_goldens():
+    assert G.check_align(O.orc_ksw_align_batch) > 2000
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="compiled reference only exists in the build container")
+def test_oracle_ksw_align_vs_live_reference():
+    import dpgen
+    n = 0
+    for si, sc in enumerate(dpgen.ALIGN_SCORES):
+        p = dpgen.align_params(sc)
+        pairs, xs = dpgen.align_cases(900 + si, 150, match=sc[0])
+        tasks, keep = ffi.make_align_tasks(pairs, xs)
+        got = O.orc_ksw_align_batch(p, tasks)
+        for i, ((q, t), x) in enumerate(zip(pairs, xs)):
+            if got[i]["qe"] >= len(q):      # undefined in the reference (it would reverse memory behind the query)
+                continue
+            assert tuple(int(v) for v in got[i]) == O.ref_ksw_align(p, q, t, x), (sc, i)
+            n += 1
+    assert n > 1000
