@@ -16,6 +16,7 @@ int main(int argc, char** argv) {
         ops->ksw_extend_batch = alfa_ksw_extend_batch;
         ops->ksw_nw_batch = alfa_ksw_nw_batch;
         ops->ksw_global_batch = alfa_ksw_global_batch;
+        ops->ksw_align_batch = alfa_ksw_align_batch;
         ops->free_fn = alfa_free;
         ops->last_error = alfa_last_error;
         return 0;

@@ -163,6 +163,20 @@ void HotSched::flush() {
         stats_.glob_calls++; stats_.glob_tasks += (int64_t)glob_.size();
         glob_.clear();
     }
+    if (!align_.empty()) {
+        // ksw_align is called with alnOptions.openGap / extendGap as they are (src/mapper.cpp:1572,2197): negative numbers,
+        // the opposite sign of what the other three calls get
+        alfa_dp_params ap = prm_;
+        ap.gapo = -prm_.gapo; ap.gape = -prm_.gape;
+        std::vector<alfa_align_task> t(align_.size());
+        std::vector<alfa_kswr> r(align_.size());
+        for (size_t i = 0; i < align_.size(); ++i) t[i] = align_[i].t;
+        int rc = ops_.ksw_align_batch(&ap, t.data(), (int)t.size(), r.data());
+        if (rc) die(ops_, "alfa_ksw_align_batch", rc);
+        for (size_t i = 0; i < align_.size(); ++i) *align_[i].out = r[i];
+        stats_.align_calls++; stats_.align_tasks += (int64_t)align_.size();
+        align_.clear();
+    }
     stats_.hot_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 

@@ -1,5 +1,5 @@
 // hot_sched.h -- fiber scheduler that turns the mapper's per-read, synchronous-looking hot-path calls
-// (sa.SMAM(...), ksw_extend(...), ksw_nw(...), ksw_global(...)) into large batches for libalfa_hot.
+// (sa.SMAM(...), ksw_extend(...), ksw_nw(...), ksw_global(...), ksw_align(...)) into large batches for libalfa_hot.
 //
 // The reference maps one read per kt_for work item and calls the hot path synchronously
 // (src/main.cpp:87-104,126).  A GPU needs >=10^4 independent calls in flight, so every read is mapped
@@ -26,6 +26,7 @@ struct HotOps {
     int (*ksw_extend_batch)(const alfa_dp_params*, const alfa_dp_task*, int, alfa_extend_result*) = nullptr;
     int (*ksw_nw_batch)(const alfa_dp_params*, const alfa_dp_task*, int, int32_t*) = nullptr;
     int (*ksw_global_batch)(const alfa_dp_params*, const alfa_dp_task*, int, int32_t*, uint32_t**, int32_t*, int64_t*) = nullptr;
+    int (*ksw_align_batch)(const alfa_dp_params*, const alfa_align_task*, int, alfa_kswr*) = nullptr;
     void (*free_fn)(void*) = nullptr;
     const char* (*last_error)() = nullptr;
 };
@@ -38,10 +39,11 @@ struct SeedReq {
 struct ExtendReq { alfa_dp_task t; alfa_extend_result* out; };
 struct NwReq { alfa_dp_task t; int32_t* out; };
 struct GlobalReq { alfa_dp_task t; int32_t* score; std::vector<uint32_t>* cigar; };
+struct AlignReq { alfa_align_task t; alfa_kswr* out; };
 
 struct SchedStats {
     int64_t rounds = 0, seed_calls = 0, seed_queries = 0, ext_calls = 0, ext_tasks = 0, nw_calls = 0, nw_tasks = 0, glob_calls = 0,
-            glob_tasks = 0;
+            glob_tasks = 0, align_calls = 0, align_tasks = 0;
     double hot_seconds = 0;   // wall time spent inside the batch entry points
 };
 
@@ -57,6 +59,7 @@ class HotSched {
     void submit_extend(const ExtendReq& r) { ext_.push_back(r); }
     void submit_nw(const NwReq& r) { nw_.push_back(r); }
     void submit_global(const GlobalReq& r) { glob_.push_back(r); }
+    void submit_align(const AlignReq& r) { align_.push_back(r); }
     void wait();              // returns when every request submitted by this fiber has been answered
     const SchedStats& stats() const { return stats_; }
     // when set, every DP task issued is appended to <prefix>.hdr (5 x int32: kind 0 nw|1 global|2 extend, qlen, tlen, w, h0)
@@ -81,6 +84,7 @@ class HotSched {
     std::vector<ExtendReq> ext_;
     std::vector<NwReq> nw_;
     std::vector<GlobalReq> glob_;
+    std::vector<AlignReq> align_;
     SchedStats stats_;
     FILE* log_hdr_ = nullptr;
     FILE* log_seq_ = nullptr;

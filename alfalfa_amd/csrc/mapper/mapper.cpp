@@ -881,14 +881,97 @@ void Mapper::set_paired(Read& m1, Read& m2, int i, int j, bool concordant) {
     set_mate(b, a, concordant, false);
 }
 
-// pairedMatch1 src/mapper.cpp:1640-1682 (without --paired-rescue, which needs ksw_align: SURVEY 8f next #1)
+// dpWindow :1464-1510 -- where the other mate has to lie, given one mate's alignment
+static void dp_window(int64_t mateRefB, int64_t mateRefE, bool mateIsFirst, bool mateIsFw, int Plength, const PairedOpt& o,
+                      int64_t& refB, int64_t& refE, bool& otherFW) {
+    const int64_t anchor = mateIsFw ? mateRefB : mateRefE;
+    bool right;
+    if (o.orientation == PAIR_FF) { right = mateIsFirst ? mateIsFw : !mateIsFw; otherFW = mateIsFw; }
+    else if (o.orientation == PAIR_FR) { right = mateIsFw; otherFW = !mateIsFw; }
+    else { right = !mateIsFw; otherFW = !mateIsFw; }
+    if (right) { refB = anchor + o.minInsert; refE = anchor + o.maxInsert; }
+    else { refB = anchor - o.maxInsert; refE = anchor - o.minInsert; }
+    if (otherFW) refE += Plength; else refB -= Plength;
+    if (!o.overlap) { if (right) refB = std::max(refB, mateRefE); else refE = std::min(refE, mateRefB); }
+    if (!o.dovetail) { if (right) refB = std::max(refB, mateRefB); else refE = std::min(refE, mateRefE); }
+}
+
+// pairAlignmentToWindow :1542-1606 (+ bestAlignmentInWindow :1526-1540): for every still unpaired alignment, in score
+// order, align the other mate inside the window with ksw_align and pair the two when the score passes
+void Mapper::pair_alignment_to_window(Read& m1, Read& m2, const std::vector<PairInfo>& order, std::vector<PairInfo>& windowAlns,
+                                      int& alnCount, int maxAlnCount) {
+    const char* S = idx_.S();
+    const int64_t N = idx_.v->N;
+    size_t i = 0;
+    int trial = 0;
+    std::vector<uint8_t> target;
+    while (i < order.size() && alnCount < maxAlnCount && trial < opt_.maxTrial) {
+        const bool alnFirst = order[i].first;
+        Alignment* aln = alnFirst ? m1.alignments[order[i].pos] : m2.alignments[order[i].pos];
+        if (!aln->paired()) {
+            trial++;
+            int64_t refB, refE;
+            bool fw;
+            Read& windowMate = alnFirst ? m2 : m1;
+            const int Plength = (int)windowMate.sequence.length();
+            dp_window(aln->refB, aln->refE, alnFirst, !aln->rc(), Plength, popt_, refB, refE, fw);
+            int windowMatePos = -1;
+            int bestScore = -1 * (int)windowMate.sequence.size();
+            for (size_t k = 0; k < windowAlns.size(); k++)
+                if (alnFirst != windowAlns[k].first) {
+                    const Alignment* ma = windowMate.alignments[windowAlns[k].pos];
+                    if (ma->refB >= refB && ma->refE <= refE && ma->rc() != fw && ma->alignmentScore > bestScore) {
+                        windowMatePos = windowAlns[k].pos;
+                        bestScore = ma->alignmentScore;
+                    }
+                }
+            if (windowMatePos < 0) {
+                // the reference reads sa.S[refB + j] without looking at the text's bounds (:1569); positions outside it are
+                // given the code of a non-ACGT character here
+                const int tLen = (int)std::max<int64_t>(refE - refB + 1, 0);
+                target.resize((size_t)tLen);
+                for (int j = 0; j < tLen; ++j) {
+                    const int64_t p = refB + j;
+                    target[j] = (p < 0 || p >= N) ? 4 : nt4((unsigned char)S[p]);
+                }
+                const int xtra = ALFA_KSW_XSTART | (Plength * opt_.match < 250 ? ALFA_KSW_XBYTE : 0);
+                alfa_kswr r;
+                const std::vector<uint8_t>& qv = fw ? windowMate.readP : windowMate.rcReadP;
+                hot_.submit_align(AlignReq{alfa_align_task{qv.data(), target.data(), Plength, tLen, xtra}, &r});
+                hot_.wait();
+                const int editDist = (int)(opt_.errorPercent * Plength) + 1;
+                const int minScore = (int)(Plength * opt_.match + (opt_.mismatch - opt_.match) * editDist);
+                if (r.score > minScore) {
+                    Alignment* n = new Alignment();
+                    n->alignmentScore = r.score;
+                    n->qB = r.qb; n->qE = r.qe;
+                    n->refB = refB + r.tb; n->refE = refB + r.te;
+                    n->refLength = r.te - r.tb + 1;
+                    if (!fw) n->flag |= 1u << 4;
+                    windowMate.alignments.push_back(n);
+                    windowMatePos = (int)windowMate.alignments.size() - 1;
+                    windowAlns.push_back(PairInfo{!alnFirst, windowMatePos, r.score});
+                }
+            }
+            if (windowMatePos >= 0) {
+                if (alnFirst) set_paired(m1, m2, order[i].pos, windowMatePos, true);
+                else set_paired(m1, m2, windowMatePos, order[i].pos, true);
+                trial = 0;
+                alnCount++;
+            }
+        }
+        i++;
+    }
+}
+
+// pairedMatch1 src/mapper.cpp:1640-1682
 void Mapper::paired_match1(Read& m1, Read& m2) {
     unpaired_match(m1);
     unpaired_match(m2);
     const int alnCount1 = (int)m1.alignments.size(), alnCount2 = (int)m2.alignments.size();
     int alnCount = 0;
     const int maxPaired = opt_.alignmentCount + 1;
-    struct Info { bool first; int pos; int score; };
+    typedef PairInfo Info;
     std::vector<Info> order;
     order.reserve((size_t)(alnCount1 + alnCount2));
     for (int i = 0; i < alnCount1; i++) order.push_back(Info{true, i, m1.alignments[i]->alignmentScore});
@@ -916,6 +999,10 @@ void Mapper::paired_match1(Read& m1, Read& m2) {
             }
             i++;
         }
+    }
+    if (popt_.pairedRescue && alnCount < maxPaired && std::max(alnCount1, alnCount2) > 0) {      // :1668-1675
+        std::vector<PairInfo> fromWindow;
+        pair_alignment_to_window(m1, m2, order, fromWindow, alnCount, maxPaired);
     }
     if (popt_.discordant && alnCount < maxPaired) {
         // calculateDiscordantAlignments :1439-1462

@@ -122,7 +122,10 @@ class Mapper {
     void right_ext(const std::string& P, int& tmpQE, int64_t& tmpRE, int64_t chrEnd, int& curScore, int bandSize, int editDist);
     void postprocess(Read& read, bool paired);
     void set_local_pos(Alignment& a);
+    struct PairInfo { bool first; int pos; int score; };       // alnScoreInfo_t src/mapper.cpp:1512-1518
     void paired_match1(Read& m1, Read& m2);
+    void pair_alignment_to_window(Read& m1, Read& m2, const std::vector<PairInfo>& order, std::vector<PairInfo>& windowAlns,
+                                  int& alnCount, int maxAlnCount);
     void set_paired(Read& m1, Read& m2, int i, int j, bool concordant);
     bool is_concordant(const Alignment& a, const Alignment& b) const;
     const RefIndex& idx_;

@@ -125,8 +125,8 @@ bool parse(int argc, char** argv, Options& o) {
     if (o.aln.errorPercent < 0.0 || o.aln.errorPercent > 1.0) { fprintf(stderr, "ERROR: uncorrect value for edit distance.\n"); exit(1); }
     if (o.aln.minCoverage < 0.0 || o.aln.minCoverage > 1.0) { fprintf(stderr, "ERROR: uncorrect value for minimum coverage.\n"); exit(1); }
     if (o.paired.minInsert > o.paired.maxInsert) { fprintf(stderr, "ERROR: minimum insert size is larger than maximum insert size\n"); exit(1); }
-    if (o.paired.mode != 1 || o.paired.pairedRescue) {
-        fprintf(stderr, "ERROR: only --paired-mode 1 without --paired-rescue is implemented (the others need ksw_align; SURVEY 8f)\n");
+    if (o.paired.mode != 1) {
+        fprintf(stderr, "ERROR: only --paired-mode 1 (with or without --paired-rescue) is implemented\n");
         exit(1);
     }
     o.aln.maxAlnCount = std::max(o.aln.alignmentCount, o.aln.minTrial);      // src/options.cpp:400
@@ -444,12 +444,12 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
             const SchedStats& x = sc->stats();
             s.rounds += x.rounds; s.seed_calls += x.seed_calls; s.seed_queries += x.seed_queries; s.ext_calls += x.ext_calls;
             s.ext_tasks += x.ext_tasks; s.nw_calls += x.nw_calls; s.nw_tasks += x.nw_tasks; s.glob_calls += x.glob_calls;
-            s.glob_tasks += x.glob_tasks; s.hot_seconds += x.hot_seconds;
+            s.glob_tasks += x.glob_tasks; s.align_calls += x.align_calls; s.align_tasks += x.align_tasks; s.hot_seconds += x.hot_seconds;
         }
         fprintf(stderr, "#PHASES parse %.3f map %.3f print %.3f\n", t_parse, t_map, t_print);
-        fprintf(stderr, "#STATS rounds %ld seed_calls %ld seed_queries %ld extend %ld/%ld nw %ld/%ld global %ld/%ld hot_seconds %.3f\n",
+        fprintf(stderr, "#STATS rounds %ld seed_calls %ld seed_queries %ld extend %ld/%ld nw %ld/%ld global %ld/%ld align %ld/%ld hot_seconds %.3f\n",
                 (long)s.rounds, (long)s.seed_calls, (long)s.seed_queries, (long)s.ext_calls, (long)s.ext_tasks, (long)s.nw_calls,
-                (long)s.nw_tasks, (long)s.glob_calls, (long)s.glob_tasks, s.hot_seconds);
+                (long)s.nw_tasks, (long)s.glob_calls, (long)s.glob_tasks, (long)s.align_calls, (long)s.align_tasks, s.hot_seconds);
     }
     for (int g = 0; g < G; ++g) bind.release_ops(&ops[g]);
     alfa_host_index_free(hidx);

@@ -15,6 +15,7 @@ int main(int argc, char** argv) {
         ops->ksw_extend_batch = orc_ksw_extend_batch;
         ops->ksw_nw_batch = orc_ksw_nw_batch;
         ops->ksw_global_batch = orc_ksw_global_batch;
+        ops->ksw_align_batch = orc_ksw_align_batch;
         ops->free_fn = orc_free;
         ops->last_error = [] { return "oracle"; };
         return 0;

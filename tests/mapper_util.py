@@ -26,6 +26,14 @@ CONFIGS = {
     "454_s1_local": (1, ["-0", "454reads.fq", "--local"]),
     "454_s12_e12": (12, ["-0", "454reads.fq", "-e", "0.12"]),
     "454_s1_a5": (1, ["-0", "454reads.fq", "-a", "5"]),
+    # --paired-rescue reaches ksw_align (src/mapper.cpp:1571); goldens by tools/make_paired_goldens.py.  (The reference itself
+    # segfaults on tighter insert ranges, e.g. -I 3700 -X 4300: its rescue window runs off the text, :1569.)
+    "pe_s12_rescue": (12, ["-1", "mate1.fq", "-2", "mate2.fq", "-I", "3600", "-X", "4400", "--paired-rescue"]),
+    "pe_s1_rescue": (1, ["-1", "mate1.fq", "-2", "mate2.fq", "-I", "3600", "-X", "4400", "--paired-rescue"]),
+    "pe_s12_rescue_strict": (12, ["-1", "mate1.fq", "-2", "mate2.fq", "-I", "3600", "-X", "4400", "--paired-rescue", "-e", "0.02",
+                                  "--no-rescue", "-l", "60"]),
+    "pe_s12_rescue_a3": (12, ["-1", "mate1.fq", "-2", "mate2.fq", "-I", "3600", "-X", "4400", "--paired-rescue", "-a", "3", "--local"]),
+    "pe_s12_rescue_wide": (12, ["-1", "mate1.fq", "-2", "mate2.fq", "-I", "3000", "-X", "5000", "--paired-rescue", "-e", "0.03"]),
 }
 
 
@@ -64,3 +72,55 @@ def run_config(exe, name, extra=()):
 
 def md5(b):
     return hashlib.md5(b).hexdigest()
+
+
+# ---- synthetic paired-end set for --paired-rescue (many ksw_align calls; the lambda example makes only 12).  Inputs are
+# regenerated from a seed; the reference's SAM md5 is committed (tests/golden/sam_synth_md5.json, tools/make_paired_goldens.py)
+SYNTH_CONFIGS = {
+    "synpe_rescue": ["-I", "250", "-X", "650", "--paired-rescue"],
+    "synpe_rescue_local": ["-I", "250", "-X", "650", "--paired-rescue", "-a", "3", "--local", "-e", "0.05"],
+    "synpe_rescue_long": ["-I", "250", "-X", "650", "--paired-rescue", "-M", "2", "-U", "-3"],
+}
+
+
+def synth_paired():
+    """writes synpe.fa / synpe_1.fq / synpe_2.fq into the work directory (once) and returns it"""
+    import numpy as np
+    import seqgen
+    d = workdir()
+    if os.path.exists(os.path.join(d, "synpe_2.fq")):
+        return d
+    rng = np.random.default_rng(2024)
+    ref = seqgen.rand_ref(rng, 400000)
+    with open(os.path.join(d, "synpe.fa"), "w") as f:
+        f.write(">synpe\n")
+        s = ref.decode().upper()
+        for i in range(0, len(s), 70):
+            f.write(s[i:i + 70] + "\n")
+    # one mate is clean, the other often too noisy for its seeds (rescue territory) and sometimes unrelated
+    noisy = lambda r: float(r.choice([0.01, 0.06, 0.12, 0.2]))
+    m1, m2 = seqgen.sim_pairs(rng, ref, 3000, 150, 300, 600, 0.01, noisy, 3000)
+    for k in range(0, 3000, 37):
+        m2[k] = seqgen.rand_ref(rng, 150)
+    for path, reads, tag in (("synpe_1.fq", m1, 1), ("synpe_2.fq", m2, 2)):
+        with open(os.path.join(d, path), "w") as f:
+            for i, r in enumerate(reads):
+                f.write("@p%d/%d\n%s\n+\n%s\n" % (i, tag, r.decode().upper(), "I" * len(r)))
+    return d
+
+
+def run_synth(exe, name, extra=()):
+    d = synth_paired()
+    pre = os.path.join(d, "synpe_%s" % os.path.basename(exe))
+    if not os.path.exists(pre + ".aux"):
+        subprocess.run([exe, "index", "-r", "synpe.fa", "-p", pre, "-s", "12"], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+    out = os.path.join(d, "out_%s_%s.sam" % (os.path.basename(exe), name))
+    p = subprocess.run([exe, "align", "-i", pre, "-o", out, "-1", "synpe_1.fq", "-2", "synpe_2.fq"] + SYNTH_CONFIGS[name] + list(extra),
+                       cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return sam_body(out), p.stderr.decode()
+
+
+def synth_md5(name):
+    return json.load(open(os.path.join(G.GOLD, "sam_synth_md5.json")))[name]

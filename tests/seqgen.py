@@ -59,3 +59,24 @@ def seed_params(K, plen, err_percent=0.08, min_mem=40, fixed_min=False):
     else:
         sq = max((min_len - 12) // K, 1)
     return min_len, sq
+
+
+def sim_pairs(rng, ref, n, rlen, ins_lo, ins_hi, err1, err2, margin):
+    """n FR read pairs: fragment of length U[ins_lo,ins_hi] at least `margin` away from both ends of `ref`; mate 1 is the
+    fragment's left end (forward), mate 2 its right end (reverse complement); the pair as a whole is flipped half of the
+    time.  err1/err2: per-base error of the two mates (a callable gives a per-pair rate)."""
+    m1, m2 = [], []
+    L = len(ref)
+    for _ in range(n):
+        ins = int(rng.integers(ins_lo, ins_hi + 1))
+        p = int(rng.integers(margin, L - margin - ins))
+        frag = ref[p:p + ins]
+        e1 = err1(rng) if callable(err1) else err1
+        e2 = err2(rng) if callable(err2) else err2
+        a = mutate(rng, frag[:rlen], e1)
+        b = revcomp(mutate(rng, frag[-rlen:], e2))
+        if rng.random() < 0.5:
+            a, b = b, a
+        m1.append(a)
+        m2.append(b)
+    return m1, m2

@@ -19,6 +19,14 @@ def test_gpu_mapper_matches_reference_sam(gpu, name):
     assert M.md5(body) == M.golden_md5(name)
 
 
+@pytest.mark.parametrize("name", sorted(M.SYNTH_CONFIGS))
+def test_gpu_mapper_paired_rescue_synthetic(gpu, name):
+    """--paired-rescue on 3 000 synthetic pairs (hundreds of ksw_align calls): md5 of the compiled reference's records"""
+    body, err = M.run_synth(M.GPU_EXE, name, ["-t", "4", "--stats"])
+    assert M.md5(body) == M.synth_md5(name)
+    assert " align 0/0" not in err
+
+
 def test_gpu_mapper_vs_oracle_mapper_synthetic(gpu):
     """larger synthetic set (two contigs, short + long reads): product binary vs the oracle-backed host mapper"""
     d = M.workdir()

@@ -21,3 +21,12 @@ def test_output_independent_of_threads_and_fibers():
     a = M.run_config(M.CPU_EXE, "pe_s12", ["-t", "1", "--fibers", "1"])
     b = M.run_config(M.CPU_EXE, "pe_s12", ["-t", "5", "--fibers", "7"])
     assert a == b == M.golden_body("pe_s12")
+
+
+@pytest.mark.skipif(not os.path.exists(M.CPU_EXE), reason="tests/_cpu_mapper not built")
+@pytest.mark.parametrize("name", sorted(M.SYNTH_CONFIGS))
+def test_host_mapper_paired_rescue_synthetic(name):
+    """3 000 synthetic pairs, one mate often too noisy to seed: --paired-rescue issues hundreds of ksw_align calls"""
+    body, err = M.run_synth(M.CPU_EXE, name, ["-t", "8", "--stats"])
+    assert M.md5(body) == M.synth_md5(name)
+    assert " align 0/0" not in err
