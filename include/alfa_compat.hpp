@@ -6,6 +6,7 @@
 // wrappers are for bring-up and for tests, the batch forms are the product.)
 //
 //   alfa_compat::ksw_extend / ksw_nw / ksw_global   == src/ksw.h:63-106 (ksw_global's CIGAR is malloc'd: free() it)
+//   alfa_compat::ksw_align / kswr_t / KSW_X*        == src/ksw.h:6-19,63 (the query-profile cache argument must be null)
 //   alfa_compat::sparseSA::SMAM / MEM / SMEM        == src/sparseSA.h:274-283 (append to `matches`, never clear it)
 //   alfa_compat::match_t                            == src/sparseSA.h:103-110
 #pragma once
@@ -73,6 +74,21 @@ inline int ksw_global(int qlen, const uint8_t* query, int tlen, const uint8_t* t
     if (cigar) *cigar = c;          // malloc'd by the library: the caller's free() releases it, as in the reference
     else alfa_free(c);
     return s;
+}
+
+typedef alfa_kswr kswr_t;          // same seven ints (src/ksw.h:14-19)
+enum { KSW_XBYTE = ALFA_KSW_XBYTE, KSW_XSTOP = ALFA_KSW_XSTOP, KSW_XSUBO = ALFA_KSW_XSUBO, KSW_XSTART = ALFA_KSW_XSTART };
+
+// gapo / gape go through untouched: the reference's callers hand ksw_align negative numbers (src/mapper.cpp:1572) and the
+// library reproduces what its unsigned arithmetic makes of them.  `qry` (the cached query profile) must be null.
+inline kswr_t ksw_align(int qlen, uint8_t* query, int tlen, uint8_t* target, int m, const int8_t* mat, int gapo, int gape, int xtra, void** qry) {
+    if (qry) throw std::runtime_error("alfa_compat::ksw_align: the query profile cache is not supported, pass 0");
+    alfa_dp_params p;
+    fill_params(p, m, mat, gapo, gape, 0);
+    alfa_align_task t = {query, target, qlen, tlen, xtra};
+    kswr_t r;
+    must(alfa_ksw_align_batch(&p, &t, 1, &r));
+    return r;
 }
 
 // the HBM-resident index with the reference's query methods

@@ -45,6 +45,10 @@ int main(int argc, char** argv) {
         for (int k = 0; k < nc; ++k) printf(" %u", cig[k]);
         printf("\n");
         free(cig);
+        // ksw_align as src/mapper.cpp:1570-1572 calls it: negative gap numbers, KSW_XSTART, byte scores for short queries
+        const int xtra = alfa_compat::KSW_XSTART | ((int)q.size() * 1 < 250 ? alfa_compat::KSW_XBYTE : 0);
+        alfa_compat::kswr_t a = alfa_compat::ksw_align((int)q.size(), q.data(), (int)t.size(), t.data(), 5, mat, -6, -1, xtra, 0);
+        printf("A %zu %d %d %d %d %d %d %d\n", r, a.score, a.te, a.qe, a.score2, a.te2, a.tb, a.qb);
     }
     alfa_host_index_free(h);
     return 0;

@@ -1,4 +1,4 @@
-"""include/alfa_compat.hpp: the reference's own call signatures (sparseSA::SMAM/MEM/SMEM, ksw_extend/ksw_nw/ksw_global) over
+"""include/alfa_compat.hpp: the reference's own call signatures (sparseSA::SMAM/MEM/SMEM, ksw_extend/ksw_nw/ksw_global/ksw_align) over
 libalfa_hot, one call at a time, against the oracle."""
 import os
 import subprocess
@@ -46,6 +46,12 @@ def test_reference_signatures_batch_of_one(gpu):
                 exp += [(int(x["ref"]), int(x["query"]), int(x["len"])) for x in m]
             got = [tuple(int(v) for v in t.split(",")) for t in f[3:]]
             assert int(f[2]) == len(exp) and got == exp, r
+        elif f[0] == "A":
+            q, t = nt4[np.frombuffer(reads[r], np.uint8)], nt4[np.frombuffer(reads[r + 1], np.uint8)]
+            pa = ffi.default_params()
+            pa.gapo, pa.gape = -6, -1
+            tk, keep = ffi.make_align_tasks([(q, t)], ffi.KSW_XSTART | (ffi.KSW_XBYTE if len(q) < 250 else 0))
+            assert [int(v) for v in f[2:]] == [int(v) for v in O.orc_ksw_align_batch(pa, tk)[0]], r
         else:
             q, t = nt4[np.frombuffer(reads[r], np.uint8)], nt4[np.frombuffer(reads[r + 1], np.uint8)]
             w = 30 + abs(len(q) - len(t))
