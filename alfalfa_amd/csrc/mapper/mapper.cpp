@@ -582,31 +582,35 @@ int Mapper::extend_chain(const std::string& P, const std::vector<Match>& matches
     return maxAlnScore >= minScore ? maxAlnScore : -1;
 }
 
-// processLisIntervals src/mapper.cpp:1118-1204 (hasUnique :1090-1112 with an ordered map instead of kbtree)
-void Mapper::process_lis(Read& read, const std::vector<Lis>& lis, int editDist, int maxAlnCount, int minCoverage, int minScore) {
-    size_t lisIndex = 0;
-    int trialF = 0, trialR = 0;
-    std::map<int64_t, int64_t> treeF, treeR;   // read position -> seed length
-    auto has_unique = [](const Lis& l, std::map<int64_t, int64_t>& tree) {
-        bool unique = false;
-        for (const Match& s : l.matches) {
-            const int64_t q = s.query, len = s.len;
-            if (!tree.empty()) {
-                auto ub = tree.upper_bound(q);                 // kb_interval: lower = largest key <= q
-                bool hasLower = ub != tree.begin();
-                auto lower = hasLower ? std::prev(ub) : tree.end();
-                if (!hasLower || lower->first + lower->second < q + len) {
-                    if (hasLower && lower->first == q) tree.erase(lower);
-                    tree[q] = len;
-                    unique = true;
-                }
-            } else {
+// hasUnique src/mapper.cpp:1090-1112 with an ordered map (read position -> seed length) instead of the kbtree
+typedef std::map<int64_t, int64_t> QCovTree;
+template <class L>
+static bool has_unique(const L& l, QCovTree& tree) {
+    bool unique = false;
+    for (const Match& s : l.matches) {
+        const int64_t q = s.query, len = s.len;
+        if (!tree.empty()) {
+            auto ub = tree.upper_bound(q);                 // kb_interval: lower = largest key <= q
+            bool hasLower = ub != tree.begin();
+            auto lower = hasLower ? std::prev(ub) : tree.end();
+            if (!hasLower || lower->first + lower->second < q + len) {
+                if (hasLower && lower->first == q) tree.erase(lower);
                 tree[q] = len;
                 unique = true;
             }
+        } else {
+            tree[q] = len;
+            unique = true;
         }
-        return unique;
-    };
+    }
+    return unique;
+}
+
+// processLisIntervals src/mapper.cpp:1118-1204
+void Mapper::process_lis(Read& read, const std::vector<Lis>& lis, int editDist, int maxAlnCount, int minCoverage, int minScore) {
+    size_t lisIndex = 0;
+    int trialF = 0, trialR = 0;
+    QCovTree treeF, treeR;
     int maxAlnScore = 0;
     while ((int)read.alignments.size() < maxAlnCount && lisIndex < lis.size()) {
         const Lis& cluster = lis[lisIndex];
@@ -896,15 +900,58 @@ static void dp_window(int64_t mateRefB, int64_t mateRefE, bool mateIsFirst, bool
     if (!o.dovetail) { if (right) refB = std::max(refB, mateRefB); else refE = std::min(refE, mateRefE); }
 }
 
-// pairAlignmentToWindow :1542-1606 (+ bestAlignmentInWindow :1526-1540): for every still unpaired alignment, in score
-// order, align the other mate inside the window with ksw_align and pair the two when the score passes
-void Mapper::pair_alignment_to_window(Read& m1, Read& m2, const std::vector<PairInfo>& order, std::vector<PairInfo>& windowAlns,
-                                      int& alnCount, int maxAlnCount) {
+// bestAlignmentInWindow :1526-1540
+static int best_alignment_in_window(const Read& mate, const std::vector<Mapper::PairInfo>& mateAlns, bool firstMate, int64_t refB, int64_t refE,
+                                    bool fw) {
+    int best = -1;
+    int bestScore = -1 * (int)mate.sequence.size();
+    for (size_t k = 0; k < mateAlns.size(); k++)
+        if (firstMate != mateAlns[k].first) {
+            const Alignment* ma = mate.alignments[mateAlns[k].pos];
+            if (ma->refB >= refB && ma->refE <= refE && ma->rc() != fw && ma->alignmentScore > bestScore) {
+                best = mateAlns[k].pos;
+                bestScore = ma->alignmentScore;
+            }
+        }
+    return best;
+}
+
+// the ksw_align call of :1565-1590 and :2190-2210: local alignment of the mate inside the window; a new alignment (no chain:
+// postprocess runs fullDP on it) when the score passes.  Returns its index or -1.
+int Mapper::window_align(Read& windowMate, int64_t refB, int64_t refE, bool fw, int minScore) {
+    // the reference reads sa.S[refB + j] without looking at the text's bounds (:1569); positions outside it are given the
+    // code of a non-ACGT character here
     const char* S = idx_.S();
     const int64_t N = idx_.v->N;
+    const int Plength = (int)windowMate.sequence.length();
+    const int tLen = (int)std::max<int64_t>(refE - refB + 1, 0);
+    std::vector<uint8_t> target((size_t)tLen);
+    for (int j = 0; j < tLen; ++j) {
+        const int64_t p = refB + j;
+        target[j] = (p < 0 || p >= N) ? 4 : nt4((unsigned char)S[p]);
+    }
+    const int xtra = ALFA_KSW_XSTART | (Plength * opt_.match < 250 ? ALFA_KSW_XBYTE : 0);
+    alfa_kswr r;
+    const std::vector<uint8_t>& qv = fw ? windowMate.readP : windowMate.rcReadP;
+    hot_.submit_align(AlignReq{alfa_align_task{qv.data(), target.data(), Plength, tLen, xtra}, &r});
+    hot_.wait();
+    if (r.score <= minScore) return -1;
+    Alignment* n = new Alignment();
+    n->alignmentScore = r.score;
+    n->qB = r.qb; n->qE = r.qe;
+    n->refB = refB + r.tb; n->refE = refB + r.te;
+    n->refLength = r.te - r.tb + 1;
+    if (!fw) n->flag |= 1u << 4;
+    windowMate.alignments.push_back(n);
+    return (int)windowMate.alignments.size() - 1;
+}
+
+// pairAlignmentToWindow :1542-1606: for every still unpaired alignment, in score order, look for (or make, with ksw_align) an
+// alignment of the other mate inside the window and pair the two
+void Mapper::pair_alignment_to_window(Read& m1, Read& m2, const std::vector<PairInfo>& order, std::vector<PairInfo>& windowAlns,
+                                      int& alnCount, int maxAlnCount) {
     size_t i = 0;
     int trial = 0;
-    std::vector<uint8_t> target;
     while (i < order.size() && alnCount < maxAlnCount && trial < opt_.maxTrial) {
         const bool alnFirst = order[i].first;
         Alignment* aln = alnFirst ? m1.alignments[order[i].pos] : m2.alignments[order[i].pos];
@@ -915,43 +962,13 @@ void Mapper::pair_alignment_to_window(Read& m1, Read& m2, const std::vector<Pair
             Read& windowMate = alnFirst ? m2 : m1;
             const int Plength = (int)windowMate.sequence.length();
             dp_window(aln->refB, aln->refE, alnFirst, !aln->rc(), Plength, popt_, refB, refE, fw);
-            int windowMatePos = -1;
-            int bestScore = -1 * (int)windowMate.sequence.size();
-            for (size_t k = 0; k < windowAlns.size(); k++)
-                if (alnFirst != windowAlns[k].first) {
-                    const Alignment* ma = windowMate.alignments[windowAlns[k].pos];
-                    if (ma->refB >= refB && ma->refE <= refE && ma->rc() != fw && ma->alignmentScore > bestScore) {
-                        windowMatePos = windowAlns[k].pos;
-                        bestScore = ma->alignmentScore;
-                    }
-                }
+            int windowMatePos = best_alignment_in_window(windowMate, windowAlns, alnFirst, refB, refE, fw);
             if (windowMatePos < 0) {
-                // the reference reads sa.S[refB + j] without looking at the text's bounds (:1569); positions outside it are
-                // given the code of a non-ACGT character here
-                const int tLen = (int)std::max<int64_t>(refE - refB + 1, 0);
-                target.resize((size_t)tLen);
-                for (int j = 0; j < tLen; ++j) {
-                    const int64_t p = refB + j;
-                    target[j] = (p < 0 || p >= N) ? 4 : nt4((unsigned char)S[p]);
-                }
-                const int xtra = ALFA_KSW_XSTART | (Plength * opt_.match < 250 ? ALFA_KSW_XBYTE : 0);
-                alfa_kswr r;
-                const std::vector<uint8_t>& qv = fw ? windowMate.readP : windowMate.rcReadP;
-                hot_.submit_align(AlignReq{alfa_align_task{qv.data(), target.data(), Plength, tLen, xtra}, &r});
-                hot_.wait();
                 const int editDist = (int)(opt_.errorPercent * Plength) + 1;
                 const int minScore = (int)(Plength * opt_.match + (opt_.mismatch - opt_.match) * editDist);
-                if (r.score > minScore) {
-                    Alignment* n = new Alignment();
-                    n->alignmentScore = r.score;
-                    n->qB = r.qb; n->qE = r.qe;
-                    n->refB = refB + r.tb; n->refE = refB + r.te;
-                    n->refLength = r.te - r.tb + 1;
-                    if (!fw) n->flag |= 1u << 4;
-                    windowMate.alignments.push_back(n);
-                    windowMatePos = (int)windowMate.alignments.size() - 1;
-                    windowAlns.push_back(PairInfo{!alnFirst, windowMatePos, r.score});
-                }
+                windowMatePos = window_align(windowMate, refB, refE, fw, minScore);
+                if (windowMatePos >= 0)
+                    windowAlns.push_back(PairInfo{!alnFirst, windowMatePos, windowMate.alignments[windowMatePos]->alignmentScore});
             }
             if (windowMatePos >= 0) {
                 if (alnFirst) set_paired(m1, m2, order[i].pos, windowMatePos, true);
@@ -964,72 +981,373 @@ void Mapper::pair_alignment_to_window(Read& m1, Read& m2, const std::vector<Pair
     }
 }
 
-// pairedMatch1 src/mapper.cpp:1640-1682
+// pairAlignmentsOrdered :1608-1637
+void Mapper::pair_alignments_ordered(Read& m1, Read& m2, const std::vector<PairInfo>& order, int& alnCount, int maxPaired) {
+    size_t i = 0;
+    while (i < order.size() && alnCount < maxPaired) {
+        size_t j = i + 1;
+        bool paired = order[i].first ? m1.alignments[order[i].pos]->paired() : m2.alignments[order[i].pos]->paired();
+        if (!paired) {
+            while (j < order.size() && alnCount < maxPaired) {
+                if (order[i].first != order[j].first) {
+                    int i1 = order[i].first ? order[i].pos : order[j].pos;
+                    int i2 = order[i].first ? order[j].pos : order[i].pos;
+                    Alignment* a1 = m1.alignments[i1];
+                    set_local_pos(*a1);
+                    Alignment* a2 = m2.alignments[i2];
+                    set_local_pos(*a2);
+                    if (is_concordant(*a1, *a2)) { set_paired(m1, m2, i1, i2, true); alnCount++; }
+                }
+                j++;
+            }
+        }
+        i++;
+    }
+}
+
+// calculateDiscordantAlignments :1439-1462
+void Mapper::discordant_alignments(Read& m1, Read& m2) {
+    if (m1.alignments.empty() || m2.alignments.empty()) return;
+    std::sort(m1.alignments.begin(), m1.alignments.end(), cmp_aln);
+    std::sort(m2.alignments.begin(), m2.alignments.end(), cmp_aln);
+    int maxFirst = m1.alignments[0]->alignmentScore, maxSecond = m2.alignments[0]->alignmentScore;
+    size_t n1 = m1.alignments.size(), n2 = m2.alignments.size();
+    size_t i = 0;
+    while (i < n1 && m1.alignments[i]->alignmentScore == maxFirst) {
+        if (!m1.alignments[i]->concordant()) {
+            size_t j = i;
+            while (j < n2 && m2.alignments[j]->alignmentScore == maxSecond) {
+                if (!m2.alignments[j]->concordant()) set_paired(m1, m2, (int)i, (int)j, false);
+                j++;
+            }
+        }
+        i++;
+    }
+}
+
+// alignments of both mates in descending score order (compAlnScorePaired :1520)
+std::vector<Mapper::PairInfo> Mapper::score_order(const Read& m1, const Read& m2) {
+    std::vector<PairInfo> order;
+    order.reserve(m1.alignments.size() + m2.alignments.size());
+    for (size_t i = 0; i < m1.alignments.size(); i++) order.push_back(PairInfo{true, (int)i, m1.alignments[i]->alignmentScore});
+    for (size_t i = 0; i < m2.alignments.size(); i++) order.push_back(PairInfo{false, (int)i, m2.alignments[i]->alignmentScore});
+    std::sort(order.begin(), order.end(), [](const PairInfo& a, const PairInfo& b) { return a.score > b.score; });
+    return order;
+}
+
+// pairedMatch1 src/mapper.cpp:1640-1682: map both mates, pair what is concordant, rescue through windows, then discordant pairs
 void Mapper::paired_match1(Read& m1, Read& m2) {
     unpaired_match(m1);
     unpaired_match(m2);
     const int alnCount1 = (int)m1.alignments.size(), alnCount2 = (int)m2.alignments.size();
     int alnCount = 0;
     const int maxPaired = opt_.alignmentCount + 1;
-    typedef PairInfo Info;
-    std::vector<Info> order;
-    order.reserve((size_t)(alnCount1 + alnCount2));
-    for (int i = 0; i < alnCount1; i++) order.push_back(Info{true, i, m1.alignments[i]->alignmentScore});
-    for (int i = 0; i < alnCount2; i++) order.push_back(Info{false, i, m2.alignments[i]->alignmentScore});
-    std::sort(order.begin(), order.end(), [](const Info& a, const Info& b) { return a.score > b.score; });   // compAlnScorePaired :1520
-    if (alnCount1 > 0 && alnCount2 > 0) {
-        // pairAlignmentsOrdered :1608-1637
-        size_t i = 0;
-        while (i < order.size() && alnCount < maxPaired) {
-            size_t j = i + 1;
-            bool paired = order[i].first ? m1.alignments[order[i].pos]->paired() : m2.alignments[order[i].pos]->paired();
-            if (!paired) {
-                while (j < order.size() && alnCount < maxPaired) {
-                    if (order[i].first != order[j].first) {
-                        int i1 = order[i].first ? order[i].pos : order[j].pos;
-                        int i2 = order[i].first ? order[j].pos : order[i].pos;
-                        Alignment* a1 = m1.alignments[i1];
-                        set_local_pos(*a1);
-                        Alignment* a2 = m2.alignments[i2];
-                        set_local_pos(*a2);
-                        if (is_concordant(*a1, *a2)) { set_paired(m1, m2, i1, i2, true); alnCount++; }
-                    }
-                    j++;
-                }
-            }
-            i++;
-        }
-    }
+    std::vector<PairInfo> order = score_order(m1, m2);
+    if (alnCount1 > 0 && alnCount2 > 0) pair_alignments_ordered(m1, m2, order, alnCount, maxPaired);
     if (popt_.pairedRescue && alnCount < maxPaired && std::max(alnCount1, alnCount2) > 0) {      // :1668-1675
         std::vector<PairInfo> fromWindow;
         pair_alignment_to_window(m1, m2, order, fromWindow, alnCount, maxPaired);
     }
-    if (popt_.discordant && alnCount < maxPaired) {
-        // calculateDiscordantAlignments :1439-1462
-        if (!m1.alignments.empty() && !m2.alignments.empty()) {
-            std::sort(m1.alignments.begin(), m1.alignments.end(), cmp_aln);
-            std::sort(m2.alignments.begin(), m2.alignments.end(), cmp_aln);
-            int maxFirst = m1.alignments[0]->alignmentScore, maxSecond = m2.alignments[0]->alignmentScore;
-            size_t n1 = m1.alignments.size(), n2 = m2.alignments.size();
-            size_t i = 0;
-            while (i < n1 && m1.alignments[i]->alignmentScore == maxFirst) {
-                if (!m1.alignments[i]->concordant()) {
-                    size_t j = i;
-                    while (j < n2 && m2.alignments[j]->alignmentScore == maxSecond) {
-                        if (!m2.alignments[j]->concordant()) set_paired(m1, m2, (int)i, (int)j, false);
-                        j++;
+    if (popt_.discordant && alnCount < maxPaired) discordant_alignments(m1, m2);
+}
+
+// pairedMatch2 :2377-2426: map mate 1, look for mate 2 in the windows of its alignments, then the other way round
+void Mapper::paired_match2(Read& m1, Read& m2) {
+    unpaired_match(m1);
+    std::sort(m1.alignments.begin(), m1.alignments.end(), cmp_aln);
+    int alnCount = 0;
+    const int maxPaired = opt_.alignmentCount + 1;
+    auto by_score = [](const PairInfo& a, const PairInfo& b) { return a.score > b.score; };
+    std::vector<PairInfo> mate1Alns, mate2Alns;
+    for (int j = 0; j < (int)m1.alignments.size(); j++) mate1Alns.push_back(PairInfo{true, j, m1.alignments[j]->alignmentScore});
+    std::sort(mate1Alns.begin(), mate1Alns.end(), by_score);
+    pair_alignment_to_window(m1, m2, mate1Alns, mate2Alns, alnCount, maxPaired);
+    if (alnCount < maxPaired) {
+        unpaired_match(m2);
+        mate2Alns.clear();
+        for (int j = 0; j < (int)m2.alignments.size(); j++)
+            if (!m2.alignments[j]->paired()) mate2Alns.push_back(PairInfo{false, j, m2.alignments[j]->alignmentScore});
+        std::sort(mate2Alns.begin(), mate2Alns.end(), by_score);
+        pair_alignment_to_window(m1, m2, mate2Alns, mate1Alns, alnCount, maxPaired);
+    }
+    if (popt_.pairedRescue && alnCount < maxPaired && std::max((int)m1.alignments.size(), (int)m2.alignments.size()) > 0) {
+        std::vector<PairInfo> order = score_order(m1, m2);
+        pair_alignments_ordered(m1, m2, order, alnCount, maxPaired);
+    }
+    if (popt_.discordant && alnCount < maxPaired) discordant_alignments(m1, m2);
+}
+
+// isConcordantLIS :1692-1758 (its `end2` is mate1's end, :1731 -- kept)
+bool Mapper::is_concordant_lis(const Lis& a, const Lis& b, int editDist1, int editDist2) const {
+    bool firstLeft;
+    if ((popt_.orientation == PAIR_RF || popt_.orientation == PAIR_FR) && a.fw == b.fw) return false;
+    else if (popt_.orientation == PAIR_FF && a.fw != b.fw) return false;
+    if (popt_.orientation == PAIR_FF || popt_.orientation == PAIR_FR) firstLeft = a.fw;
+    else firstLeft = !a.fw;
+    if (firstLeft && b.refEnd <= a.refBegin) return false;
+    else if (!firstLeft && a.refEnd <= b.refBegin) return false;
+    const int64_t begin = std::min(a.refBegin, b.refBegin), end = std::max(a.refEnd, b.refEnd), size = end - begin + 1;
+    if (size + (editDist1 + editDist2) < popt_.minInsert || size - (editDist1 + editDist2) > popt_.maxInsert) return false;
+    const int64_t begin1 = a.refBegin, end1 = a.refEnd, begin2 = b.refBegin, end2 = a.refEnd;
+    const bool contain = (begin1 - editDist1 >= begin2 + editDist2 && end1 + editDist1 <= end2 - editDist2) ||
+                         (begin2 - editDist2 >= begin1 + editDist1 && end2 + editDist2 <= end1 - editDist1);
+    if (contain && !popt_.contain) return false;
+    const bool overlap = contain || !(end2 - editDist2 < begin1 + editDist1 || begin2 + editDist2 > end1 - editDist1);
+    if (!popt_.overlap && overlap) return false;
+    if ((firstLeft && (begin2 + editDist2 < begin1 - editDist1)) || (!firstLeft && (begin1 + editDist1 < begin2 - editDist2))) {
+        if (!overlap) return false;
+        else if (!popt_.dovetail) return false;
+    }
+    return true;
+}
+
+// the tail shared by pairedMatch3 and pairedMatch4 (:1815-1841, :2102-2134): pair by score order, optionally rescue, discordant
+void Mapper::pair_and_finish(Read& m1, Read& m2, bool withWindowRescue) {
+    int alnCount = 0;
+    const int maxPaired = opt_.alignmentCount + 1;
+    const int alnCount1 = (int)m1.alignments.size(), alnCount2 = (int)m2.alignments.size();
+    std::vector<PairInfo> order = score_order(m1, m2);
+    if (alnCount1 > 0 && alnCount2 > 0) pair_alignments_ordered(m1, m2, order, alnCount, maxPaired);
+    if (withWindowRescue && popt_.pairedRescue && alnCount < maxPaired && std::max(alnCount1, alnCount2) > 0) {
+        std::vector<PairInfo> fromWindow;
+        pair_alignment_to_window(m1, m2, order, fromWindow, alnCount, maxPaired);
+    }
+    if (popt_.discordant && alnCount < maxPaired) discordant_alignments(m1, m2);
+}
+
+// pairedMatch3 :1761-1843: candidate regions of both mates, keep the regions that pair, align those
+void Mapper::paired_match3(Read& m1, Read& m2) {
+    const int len1 = (int)m1.sequence.length(), len2 = (int)m2.sequence.length();
+    const int editDist1 = (int)(opt_.errorPercent * len1) + 1, editDist2 = (int)(opt_.errorPercent * len2) + 1;
+    std::vector<Lis> lis1, lis2, f1, f2;
+    cand_regions(m1, lis1, opt_.errorPercent);
+    cand_regions(m2, lis2, opt_.errorPercent);
+    for (size_t i = 0; i < lis1.size(); i++)
+        for (size_t j = 0; j < lis2.size(); j++)
+            if (!(lis1[i].extended && lis2[j].extended) && is_concordant_lis(lis1[i], lis2[j], editDist1, editDist2)) {
+                if (!lis1[i].extended) { f1.push_back(lis1[i]); lis1[i].extended = true; }
+                if (!lis2[j].extended) { f2.push_back(lis2[j]); lis2[j].extended = true; }
+            }
+    if (f1.empty() && f2.empty()) { paired_match1(m1, m2); return; }
+    int minScore1 = (int)(len1 * opt_.match + (opt_.mismatch - opt_.match) * (editDist1 * 1.5));
+    int minScore2 = (int)(len2 * opt_.match + (opt_.mismatch - opt_.match) * (editDist2 * 1.5));
+    process_lis(m1, f1, editDist1, opt_.maxAlnCount, 0, minScore1);
+    process_lis(m2, f2, editDist2, opt_.maxAlnCount, 0, minScore2);
+    if (m1.alignments.empty() && opt_.rescue) {
+        minScore1 = std::max(0, (int)(len1 * opt_.match + (opt_.mismatch - opt_.match) * 0.2 * len1));
+        process_lis(m1, f1, editDist1, opt_.maxAlnCount, 0, minScore1);
+    }
+    if (m2.alignments.empty() && opt_.rescue) {
+        minScore2 = std::max(0, (int)(len2 * opt_.match + (opt_.mismatch - opt_.match) * 0.2 * len2));
+        process_lis(m2, f2, editDist2, opt_.maxAlnCount, 0, minScore2);
+    }
+    pair_and_finish(m1, m2, false);
+}
+
+// processLisIntervalsSimultaneous :1857-1939: extend the two regions of a couple together and pair what they give
+void Mapper::process_lis_simultaneous(Read& m1, Read& m2, const std::vector<Lis>& lis1, const std::vector<Lis>& lis2,
+                                      const std::vector<LisCouple>& order, int maxAlnCount, double minCoveragePercent, int minScore1, int minScore2) {
+    const int len1 = (int)m1.sequence.length(), len2 = (int)m2.sequence.length();
+    const int minCoverage1 = (int)(len1 * minCoveragePercent), minCoverage2 = (int)(len2 * minCoveragePercent);
+    const int editDist1 = (int)(opt_.errorPercent * len1) + 1, editDist2 = (int)(opt_.errorPercent * len2) + 1;
+    size_t lisIndex = 0;
+    int trial = 0, maxAlnScore = 0, alnCount = 0;
+    while (alnCount < maxAlnCount && lisIndex < order.size()) {
+        const Lis& c1 = lis1[order[lisIndex].first];
+        const Lis& c2 = lis2[order[lisIndex].second];
+        if (trial < opt_.maxTrial) {
+            int64_t cs1, ce1, cs2, ce2;
+            idx_.chrom_bounds(c1.matches[0].ref, cs1, ce1);
+            idx_.chrom_bounds(c2.matches[0].ref, cs2, ce2);
+            const size_t base1 = m1.alignments.size(), base2 = m2.alignments.size();
+            int r1 = extend_chain(c1.fw ? m1.sequence : m1.rcSequence, c1.matches, editDist1, minScore1, minCoverage1, cs1, ce1, m1, c1.fw);
+            int r2 = extend_chain(c2.fw ? m2.sequence : m2.rcSequence, c2.matches, editDist2, minScore2, minCoverage2, cs2, ce2, m2, c2.fw);
+            if (base1 == m1.alignments.size() && base2 < m2.alignments.size() && opt_.rescue) {          // the lowered bound stays (:1904)
+                minScore1 = std::max(0, (int)(len1 * opt_.match + (opt_.mismatch - opt_.match) * 0.2 * len1));
+                r1 = extend_chain(c1.fw ? m1.sequence : m1.rcSequence, c1.matches, editDist1, minScore1, minCoverage1, cs1, ce1, m1, c1.fw);
+            } else if (base1 < m1.alignments.size() && base2 == m2.alignments.size() && opt_.rescue) {
+                minScore2 = std::max(0, (int)(len2 * opt_.match + (opt_.mismatch - opt_.match) * 0.2 * len2));
+                r2 = extend_chain(c2.fw ? m2.sequence : m2.rcSequence, c2.matches, editDist2, minScore2, minCoverage2, cs2, ce2, m2, c2.fw);
+            }
+            if (base1 < m1.alignments.size() && base2 < m2.alignments.size()) {
+                const size_t max1 = m1.alignments.size(), max2 = m2.alignments.size();
+                for (size_t i = base1; i < max1; i++)
+                    for (size_t j = base2; j < max2; j++) {
+                        Alignment* a1 = m1.alignments[i];
+                        set_local_pos(*a1);
+                        Alignment* a2 = m2.alignments[j];
+                        set_local_pos(*a2);
+                        if (is_concordant(*a1, *a2)) { set_paired(m1, m2, (int)i, (int)j, true); alnCount++; }
+                    }
+            }
+            trial++;
+            const int ret = r1 + r2;
+            if (ret >= 0 && (!opt_.maxTrialBest || maxAlnScore < ret)) trial = 0;
+            maxAlnScore = std::max(maxAlnScore, ret);
+        }
+        lisIndex++;
+    }
+}
+
+// pairedMatch6 :1941-1985: couples of regions that pair, best summed score first
+void Mapper::paired_match6(Read& m1, Read& m2) {
+    const int len1 = (int)m1.sequence.length(), len2 = (int)m2.sequence.length();
+    const int editDist1 = (int)(opt_.errorPercent * len1) + 1, editDist2 = (int)(opt_.errorPercent * len2) + 1;
+    std::vector<Lis> lis1, lis2;
+    cand_regions(m1, lis1, opt_.errorPercent);
+    cand_regions(m2, lis2, opt_.errorPercent);
+    std::vector<LisCouple> couples;
+    for (size_t i = 0; i < lis1.size(); i++)
+        for (size_t j = 0; j < lis2.size(); j++)
+            if (!(lis1[i].extended && lis2[j].extended) && is_concordant_lis(lis1[i], lis2[j], editDist1, editDist2))
+                couples.push_back(LisCouple{(int)i, (int)j, lis1[i].score + lis2[j].score});
+    if (couples.empty()) { paired_match1(m1, m2); return; }
+    std::sort(couples.begin(), couples.end(), [](const LisCouple& a, const LisCouple& b) { return a.score > b.score; });      // compLIScouple :1853
+    const int minScore1 = (int)(len1 * opt_.match + (opt_.mismatch - opt_.match) * (editDist1 * 1.5));
+    const int minScore2 = (int)(len2 * opt_.match + (opt_.mismatch - opt_.match) * (editDist2 * 1.5));
+    process_lis_simultaneous(m1, m2, lis1, lis2, couples, opt_.maxAlnCount, 0, minScore1, minScore2);
+    if (popt_.discordant && m1.pairedAlignmentCount < opt_.alignmentCount + 1) discordant_alignments(m1, m2);
+}
+
+// processLisIntervalsPaired :1987-2050 (andPair = false) and processLisIntervalsAndPair :2225-2312 (andPair = true): the regions
+// of both mates in one score order; the second form looks for the other mate right after every extension
+void Mapper::process_lis_both(Read& m1, Read& m2, std::vector<Lis>& lis1, std::vector<Lis>& lis2, const std::vector<PairInfo>& order,
+                              int maxAlnCount, double minCoveragePercent, int minScore1, int minScore2, bool andPair) {
+    const int len1 = (int)m1.sequence.length(), len2 = (int)m2.sequence.length();
+    const int minCoverage1 = (int)(len1 * minCoveragePercent), minCoverage2 = (int)(len2 * minCoveragePercent);
+    const int editDist1 = (int)(opt_.errorPercent * len1) + 1, editDist2 = (int)(opt_.errorPercent * len2) + 1;
+    size_t lisIndex = 0;
+    int trialF = 0, trialR = 0, maxAlnScore = 0, alnCount = 0;
+    QCovTree treeF, treeR;
+    std::vector<PairInfo> mate1Alns, mate2Alns;
+    while (alnCount < maxAlnCount && lisIndex < order.size()) {
+        const bool first = order[lisIndex].first;
+        Lis& cluster = first ? lis1[order[lisIndex].pos] : lis2[order[lisIndex].pos];
+        const bool unique = has_unique(cluster, cluster.fw ? treeF : treeR);
+        const int trial = cluster.fw ? trialF : trialR;
+        const bool highCoverage = first ? cluster.score >= minCoverage1 : cluster.score >= minCoverage2;
+        const bool criterium = (trial < opt_.maxTrial || unique) && (cluster.matches.size() > 1 || highCoverage);
+        if (criterium && !(andPair && cluster.extended)) {
+            int64_t cs, ce;
+            idx_.chrom_bounds(cluster.matches[0].ref, cs, ce);
+            int ret;
+            if (first) {
+                const size_t extendCount = m1.alignments.size();
+                ret = extend_chain(cluster.fw ? m1.sequence : m1.rcSequence, cluster.matches, editDist1, minScore1, minCoverage1, cs, ce, m1, cluster.fw);
+                if (andPair) {
+                    const size_t lastAln = m1.alignments.size();
+                    for (size_t i = extendCount; i < lastAln; i++) {          // always the first new alignment (:2280-2282), kept
+                        mate1Alns.push_back(PairInfo{true, (int)extendCount, m1.alignments[extendCount]->alignmentScore});
+                        find_or_align_mate(m1, m2, true, lis2, minScore2, mate2Alns, (int)extendCount);
                     }
                 }
-                i++;
+            } else {
+                const size_t extendCount = m2.alignments.size();
+                ret = extend_chain(cluster.fw ? m2.sequence : m2.rcSequence, cluster.matches, editDist2, minScore2, minCoverage2, cs, ce, m2, cluster.fw);
+                if (andPair) {
+                    const size_t lastAln = m2.alignments.size();
+                    for (size_t i = extendCount; i < lastAln; i++) {          // appended to mate 1's list (:2292-2294), kept
+                        mate1Alns.push_back(PairInfo{false, (int)extendCount, m2.alignments[extendCount]->alignmentScore});
+                        find_or_align_mate(m2, m1, false, lis1, minScore1, mate1Alns, (int)extendCount);
+                    }
+                }
+            }
+            if (andPair) cluster.extended = true;
+            if (cluster.fw) trialF++; else trialR++;
+            if (ret >= 0 && (!opt_.maxTrialBest || maxAlnScore < ret)) {
+                if (cluster.fw) trialF = 0; else trialR = 0;
+            }
+            alnCount = (int)(m1.alignments.size() + m2.alignments.size());
+            maxAlnScore = std::max(maxAlnScore, ret);
+        }
+        lisIndex++;
+    }
+}
+
+// findOrAlignMateToAlignment :2151-2223 (bestLISInWindow :2137-2149)
+void Mapper::find_or_align_mate(Read& alignmentMate, Read& windowMate, bool alnMateFirst, std::vector<Lis>& lisWindow, int minScore,
+                                std::vector<PairInfo>& windowAlns, int alignmentIndex) {
+    Alignment* aln = alignmentMate.alignments[alignmentIndex];
+    int64_t refB, refE;
+    bool fw;
+    const int Plength = (int)windowMate.sequence.length();
+    dp_window(aln->refB, aln->refE, alnMateFirst, !aln->rc(), Plength, popt_, refB, refE, fw);
+    int windowMatePos = best_alignment_in_window(windowMate, windowAlns, alnMateFirst, refB, refE, fw);
+    int windowCount = 1;
+    if (windowMatePos < 0) {
+        const int editDist = (int)(opt_.errorPercent * Plength) + 1;
+        int lisPos = -1, bestScore = -10000;
+        for (size_t i = 0; i < lisWindow.size(); i++)
+            if (lisWindow[i].refBegin + editDist >= refB && lisWindow[i].refEnd - editDist <= refE && lisWindow[i].fw == fw &&
+                lisWindow[i].score > bestScore) {
+                lisPos = (int)i;
+                bestScore = lisWindow[i].score;
+            }
+        if (lisPos >= 0) {
+            int64_t cs, ce;
+            idx_.chrom_bounds(lisWindow[lisPos].matches[0].ref, cs, ce);
+            const size_t extendCount = windowMate.alignments.size();
+            extend_chain(lisWindow[lisPos].fw ? windowMate.sequence : windowMate.rcSequence, lisWindow[lisPos].matches, editDist, minScore,
+                         (int)(Plength * 0.01), cs, ce, windowMate, lisWindow[lisPos].fw);
+            if (windowMate.alignments.size() > extendCount) {
+                lisWindow[lisPos].extended = true;
+                windowMatePos = (int)extendCount;
+                windowCount = (int)(windowMate.alignments.size() - extendCount);
             }
         }
     }
+    if (windowMatePos < 0 && popt_.pairedRescue) windowMatePos = window_align(windowMate, refB, refE, fw, minScore);
+    if (windowMatePos >= 0)
+        for (int i = 0; i < windowCount; i++) {
+            windowAlns.push_back(PairInfo{!alnMateFirst, windowMatePos + i, windowMate.alignments[windowMatePos + i]->alignmentScore});
+            if (alnMateFirst) set_paired(alignmentMate, windowMate, alignmentIndex, windowMatePos + i, true);
+            else set_paired(windowMate, alignmentMate, windowMatePos + i, alignmentIndex, true);
+        }
+}
+
+// pairedMatch4 :2053-2135 (andPair = false) and pairedMatch5 :2315-2373 (andPair = true)
+void Mapper::paired_match45(Read& m1, Read& m2, bool andPair) {
+    std::vector<Lis> lis1, lis2;
+    cand_regions(m1, lis1, opt_.errorPercent);
+    cand_regions(m2, lis2, opt_.errorPercent);
+    std::vector<PairInfo> order;
+    order.reserve(lis1.size() + lis2.size());
+    for (size_t i = 0; i < lis1.size(); i++) order.push_back(PairInfo{true, (int)i, lis1[i].score});
+    for (size_t i = 0; i < lis2.size(); i++) order.push_back(PairInfo{false, (int)i, lis2[i].score});
+    std::sort(order.begin(), order.end(), [](const PairInfo& a, const PairInfo& b) { return a.score > b.score; });
+    const int len1 = (int)m1.sequence.length(), len2 = (int)m2.sequence.length();
+    const int editDist1 = (int)(opt_.errorPercent * len1) + 1, editDist2 = (int)(opt_.errorPercent * len2) + 1;
+    int minScore1 = (int)(len1 * opt_.match + (opt_.mismatch - opt_.match) * editDist1);
+    int minScore2 = (int)(len2 * opt_.match + (opt_.mismatch - opt_.match) * editDist2);
+    process_lis_both(m1, m2, lis1, lis2, order, opt_.maxAlnCount, opt_.minCoverage, minScore1, minScore2, andPair);
+    if (m1.alignments.empty() && !m2.alignments.empty() && opt_.rescue) {
+        minScore1 = std::max(0, (int)(len1 * opt_.match + (opt_.mismatch - opt_.match) * 0.2 * len1));
+        process_lis(m1, lis1, editDist1, 20, (int)(len1 * 0.01), minScore1);
+    } else if (m2.alignments.empty() && !m1.alignments.empty() && opt_.rescue) {
+        minScore2 = std::max(0, (int)(len2 * opt_.match + (opt_.mismatch - opt_.match) * 0.2 * len2));
+        process_lis(m2, lis2, editDist2, 20, (int)(len1 * 0.01), minScore2);          // mate 1's length (:2089, :2352), kept
+    }
+    if (m1.alignments.empty() && m2.alignments.empty() && popt_.pairedRescue) {
+        minScore1 = std::max(0, (int)(len1 * opt_.match + (opt_.mismatch - opt_.match) * 0.2 * len1));
+        minScore2 = std::max(0, (int)(len2 * opt_.match + (opt_.mismatch - opt_.match) * 0.2 * len2));
+        process_lis_both(m1, m2, lis1, lis2, order, 20, 0.01, minScore1, minScore2, andPair);
+    }
+    if (!andPair) { pair_and_finish(m1, m2, true); return; }
+    const int alnCount = std::max(m1.pairedAlignmentCount, m2.pairedAlignmentCount);
+    if (popt_.discordant && alnCount < opt_.alignmentCount + 1) discordant_alignments(m1, m2);
 }
 
 void Mapper::map_paired(Read& m1, Read& m2) {
     m1.init();
     m2.init();
-    paired_match1(m1, m2);
+    switch (popt_.mode) {                 // pairedMatch :2429-2451
+        case 2: paired_match2(m1, m2); break;
+        case 3: paired_match3(m1, m2); break;
+        case 4: paired_match45(m1, m2, false); break;
+        case 5: paired_match45(m1, m2, true); break;
+        case 6: paired_match6(m1, m2); break;
+        default: paired_match1(m1, m2);
+    }
     postprocess(m1, true);
     postprocess(m2, true);
 }

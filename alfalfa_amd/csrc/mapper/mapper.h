@@ -104,12 +104,14 @@ class Mapper {
     Mapper(const RefIndex& idx, const AlignOpt& a, const PairedOpt& p, HotSched& hot) : idx_(idx), opt_(a), popt_(p), hot_(hot) {}
     // map_unpaired: unpairedMatch + postprocess (src/main.cpp:87-104)
     void map_unpaired(Read& read);
-    // map_paired: pairedMatch (mode 1) + postprocess of both mates (src/main.cpp:179-195)
+    // map_paired: pairedMatch (modes 1..6) + postprocess of both mates (src/main.cpp:179-195)
     void map_paired(Read& m1, Read& m2);
+
+    struct PairInfo { bool first; int pos; int score; };       // alnScoreInfo_t src/mapper.cpp:1512-1518
 
    private:
     struct Lis {                  // lis_t src/mapper.h:42-65
-        int score = 0; bool fw = true; int64_t refBegin = 0, refEnd = 0; std::vector<Match> matches;
+        int score = 0; bool fw = true; int64_t refBegin = 0, refEnd = 0; bool extended = false; std::vector<Match> matches;
     };
     void unpaired_match(Read& read);
     void seeds_both_strands(const std::string& P, const std::string& Prc, int min_len, std::vector<Match>& fw, std::vector<Match>& rc);
@@ -122,10 +124,26 @@ class Mapper {
     void right_ext(const std::string& P, int& tmpQE, int64_t& tmpRE, int64_t chrEnd, int& curScore, int bandSize, int editDist);
     void postprocess(Read& read, bool paired);
     void set_local_pos(Alignment& a);
-    struct PairInfo { bool first; int pos; int score; };       // alnScoreInfo_t src/mapper.cpp:1512-1518
     void paired_match1(Read& m1, Read& m2);
+    void paired_match2(Read& m1, Read& m2);
+    void paired_match3(Read& m1, Read& m2);
+    void paired_match45(Read& m1, Read& m2, bool andPair);
+    void paired_match6(Read& m1, Read& m2);
+    struct LisCouple { int first, second, score; };            // LIScouple_t src/mapper.cpp:1845-1851
     void pair_alignment_to_window(Read& m1, Read& m2, const std::vector<PairInfo>& order, std::vector<PairInfo>& windowAlns,
                                   int& alnCount, int maxAlnCount);
+    void pair_alignments_ordered(Read& m1, Read& m2, const std::vector<PairInfo>& order, int& alnCount, int maxPaired);
+    void discordant_alignments(Read& m1, Read& m2);
+    static std::vector<PairInfo> score_order(const Read& m1, const Read& m2);
+    void pair_and_finish(Read& m1, Read& m2, bool withWindowRescue);
+    int window_align(Read& windowMate, int64_t refB, int64_t refE, bool fw, int minScore);
+    bool is_concordant_lis(const Lis& a, const Lis& b, int editDist1, int editDist2) const;
+    void process_lis_simultaneous(Read& m1, Read& m2, const std::vector<Lis>& lis1, const std::vector<Lis>& lis2,
+                                  const std::vector<LisCouple>& order, int maxAlnCount, double minCoveragePercent, int minScore1, int minScore2);
+    void process_lis_both(Read& m1, Read& m2, std::vector<Lis>& lis1, std::vector<Lis>& lis2, const std::vector<PairInfo>& order,
+                          int maxAlnCount, double minCoveragePercent, int minScore1, int minScore2, bool andPair);
+    void find_or_align_mate(Read& alignmentMate, Read& windowMate, bool alnMateFirst, std::vector<Lis>& lisWindow, int minScore,
+                            std::vector<PairInfo>& windowAlns, int alignmentIndex);
     void set_paired(Read& m1, Read& m2, int i, int j, bool concordant);
     bool is_concordant(const Alignment& a, const Alignment& b) const;
     const RefIndex& idx_;

@@ -125,8 +125,8 @@ bool parse(int argc, char** argv, Options& o) {
     if (o.aln.errorPercent < 0.0 || o.aln.errorPercent > 1.0) { fprintf(stderr, "ERROR: uncorrect value for edit distance.\n"); exit(1); }
     if (o.aln.minCoverage < 0.0 || o.aln.minCoverage > 1.0) { fprintf(stderr, "ERROR: uncorrect value for minimum coverage.\n"); exit(1); }
     if (o.paired.minInsert > o.paired.maxInsert) { fprintf(stderr, "ERROR: minimum insert size is larger than maximum insert size\n"); exit(1); }
-    if (o.paired.mode != 1) {
-        fprintf(stderr, "ERROR: only --paired-mode 1 (with or without --paired-rescue) is implemented\n");
+    if (o.paired.mode < 1 || o.paired.mode > 6) {                            // src/options.cpp:396-397
+        fprintf(stderr, "ERROR: chosen paired-end mode not supported.\n");
         exit(1);
     }
     o.aln.maxAlnCount = std::max(o.aln.alignmentCount, o.aln.minTrial);      // src/options.cpp:400

@@ -33,6 +33,11 @@ CONFIGS = {
     "pe_s12_rescue_strict": (12, ["-1", "mate1.fq", "-2", "mate2.fq", "-I", "3600", "-X", "4400", "--paired-rescue", "-e", "0.02",
                                   "--no-rescue", "-l", "60"]),
     "pe_s12_rescue_a3": (12, ["-1", "mate1.fq", "-2", "mate2.fq", "-I", "3600", "-X", "4400", "--paired-rescue", "-a", "3", "--local"]),
+    # paired modes 3-6 (src/mapper.cpp:1761-2373); mode 2 makes the reference segfault on this input
+    "pe_s12_mode3": (12, ["-1", "mate1.fq", "-2", "mate2.fq", "-I", "3600", "-X", "4400", "--paired-mode", "3"]),
+    "pe_s12_mode4_rescue": (12, ["-1", "mate1.fq", "-2", "mate2.fq", "-I", "3600", "-X", "4400", "--paired-mode", "4", "--paired-rescue"]),
+    "pe_s12_mode5_rescue": (12, ["-1", "mate1.fq", "-2", "mate2.fq", "-I", "3600", "-X", "4400", "--paired-mode", "5", "--paired-rescue"]),
+    "pe_s1_mode6_rescue": (1, ["-1", "mate1.fq", "-2", "mate2.fq", "-I", "3600", "-X", "4400", "--paired-mode", "6", "--paired-rescue"]),
     "pe_s12_rescue_wide": (12, ["-1", "mate1.fq", "-2", "mate2.fq", "-I", "3000", "-X", "5000", "--paired-rescue", "-e", "0.03"]),
 }
 
@@ -80,6 +85,12 @@ SYNTH_CONFIGS = {
     "synpe_rescue": ["-I", "250", "-X", "650", "--paired-rescue"],
     "synpe_rescue_local": ["-I", "250", "-X", "650", "--paired-rescue", "-a", "3", "--local", "-e", "0.05"],
     "synpe_rescue_long": ["-I", "250", "-X", "650", "--paired-rescue", "-M", "2", "-U", "-3"],
+    "synpe_mode2_rescue": ["-I", "250", "-X", "650", "--paired-rescue", "--paired-mode", "2"],
+    "synpe_mode3": ["-I", "250", "-X", "650", "--paired-mode", "3"],
+    "synpe_mode4_rescue": ["-I", "250", "-X", "650", "--paired-rescue", "--paired-mode", "4"],
+    "synpe_mode5_rescue": ["-I", "250", "-X", "650", "--paired-rescue", "--paired-mode", "5"],
+    "synpe_mode5": ["-I", "250", "-X", "650", "--paired-mode", "5", "-a", "2"],
+    "synpe_mode6_rescue": ["-I", "250", "-X", "650", "--paired-rescue", "--paired-mode", "6"],
 }
 
 
@@ -97,8 +108,10 @@ def synth_paired():
         s = ref.decode().upper()
         for i in range(0, len(s), 70):
             f.write(s[i:i + 70] + "\n")
-    # one mate is clean, the other often too noisy for its seeds (rescue territory) and sometimes unrelated
-    noisy = lambda r: float(r.choice([0.01, 0.06, 0.12, 0.2]))
+    # one mate is clean; the other is often seedless but alignable without gaps (what the rescue finds), noisy, or unrelated
+    def noisy(r):
+        u = r.random()
+        return "periodic" if u < 0.35 else float(r.choice([0.01, 0.06, 0.12, 0.2]))
     m1, m2 = seqgen.sim_pairs(rng, ref, 3000, 150, 300, 600, 0.01, noisy, 3000)
     for k in range(0, 3000, 37):
         m2[k] = seqgen.rand_ref(rng, 150)

@@ -74,7 +74,14 @@ def sim_pairs(rng, ref, n, rlen, ins_lo, ins_hi, err1, err2, margin):
         e1 = err1(rng) if callable(err1) else err1
         e2 = err2(rng) if callable(err2) else err2
         a = mutate(rng, frag[:rlen], e1)
-        b = revcomp(mutate(rng, frag[-rlen:], e2))
+        if e2 == "periodic":        # a substitution every 14..18 bases and no indel: no seed of 20+, yet a high ungapped score
+            x = np.frombuffer(frag[-rlen:], dtype=np.uint8).copy()
+            step = int(rng.integers(14, 19))
+            for q in range(int(rng.integers(0, step)), len(x), step):
+                x[q] = ACGT[(int(np.nonzero(ACGT == x[q])[0][0]) + int(rng.integers(1, 4))) % 4]
+            b = revcomp(x.tobytes())
+        else:
+            b = revcomp(mutate(rng, frag[-rlen:], e2))
         if rng.random() < 0.5:
             a, b = b, a
         m1.append(a)

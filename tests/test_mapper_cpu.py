@@ -25,8 +25,8 @@ def test_output_independent_of_threads_and_fibers():
 
 @pytest.mark.skipif(not os.path.exists(M.CPU_EXE), reason="tests/_cpu_mapper not built")
 @pytest.mark.parametrize("name", sorted(M.SYNTH_CONFIGS))
-def test_host_mapper_paired_rescue_synthetic(name):
-    """3 000 synthetic pairs, one mate often too noisy to seed: --paired-rescue issues hundreds of ksw_align calls"""
+def test_host_mapper_paired_modes_synthetic(name):
+    """3 000 synthetic pairs, one mate often seedless: paired modes 1-6; --paired-rescue issues hundreds of ksw_align calls"""
     body, err = M.run_synth(M.CPU_EXE, name, ["-t", "8", "--stats"])
     assert M.md5(body) == M.synth_md5(name)
-    assert " align 0/0" not in err
+    assert ("rescue" not in name) or " align 0/0" not in err
