@@ -26,7 +26,8 @@
 //         read's workgroup between the parallel traversal and the parallel counting stages.
 // Indexes without a child table (--no-child) take the binary-search descent (traverse :701-728, top_down_faster :614-666)
 // for SMAM and MEM.  On suffix-link indexes (--suflink) the prefixes of a phase form a chain (smam_suflink_kernel: lane =
-// (read, phase)).  SMEMP (unreachable from the reference's command line) has no kernel.
+// (read, phase)).  SMEMP (unreachable from the reference's command line): smemp_count_kernel, same three stages as SMEM with
+// the stack of traverse_keep re-derived instead of stored.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -1073,6 +1074,202 @@ __global__ __launch_bounds__(SEED_BLOCK) void smem_count_kernel(DIdx X, const Se
     if (tid == 0) read_total[r] = running;
 }
 
+// ---------------------------------------------------------------- SMEMP (sparseSA.cpp:1211-1254; unreachable from the reference's CLI)
+// traverse_keep  sparseSA.cpp:793-845: the descent of traverse_faster that also keeps the stack of the lcp-intervals it
+// passes (those of at most maxBr suffixes).  collectIntervals (:968-990) walks that stack from the deepest entry upwards
+// while two conditions hold that are both monotone along the stack (interval size grows, depth shrinks), so the entries it
+// uses are exactly those satisfying them: nothing has to be stored.  `ring(lower, upper)` is called for every pair of
+// adjacent stack entries in push order; `have`/`back` return whether the stack ended non-empty and its last entry.
+template <class PAT, class F>
+__device__ void traverse_stack(const DIdx& X, const PAT& P, int prefix, IvalD mli, int min_len, int maxBr, F&& ring, bool& have, IvalD& back) {
+    IvalD cur = mli;
+    int cnt = 1;
+    back = mli;
+    auto size = [](const IvalD& v) { return v.end - v.start + 1; };
+    auto push = [&](const IvalD& nw) { if (cnt > 0) ring(back, nw); back = nw; ++cnt; };
+    if (size(cur) > maxBr) cnt = 0;
+    have = cnt > 0;
+    if (cur.depth >= min_len) return;
+    int c = prefix + cur.depth;
+    bool found = c < P.len;
+    const int curLCP = cur.start != cur.end ? ival_lcp(X, cur.start, cur.end) : -1;
+    if (found && cur.start != cur.end && curLCP == cur.depth) {
+        found = td_child(X, P.at(c), cur.start, cur.end, cur.depth);
+        if (found && size(cur) <= maxBr) push(cur);
+    } else if (found) {
+        found = P.at(c) == d_s(X, (int64_t)X.SA[cur.start] + cur.depth);
+    }
+    bool mism = false;
+    while (found && !mism && c < P.len && cur.depth < min_len) {
+        ++c; ++cur.depth;
+        if (cur.start != cur.end) {
+            const int childLCP = ival_lcp(X, cur.start, cur.end);
+            const int minimum = childLCP < min_len ? childLCP : min_len;
+            const int64_t sa0 = (int64_t)X.SA[cur.start];
+            while (!mism && c < P.len && cur.depth < minimum) {
+                mism = d_s(X, sa0 + cur.depth) != P.at(c);
+                ++c; cur.depth += !mism;
+            }
+            found = c < P.len && !mism && cur.depth < min_len && td_child(X, P.at(c), cur.start, cur.end, cur.depth);
+            if (found && size(cur) <= maxBr) push(cur);
+        } else {
+            const int64_t sa0 = (int64_t)X.SA[cur.start];
+            while (!mism && c < P.len && cur.depth < min_len) {
+                const int64_t pos = sa0 + cur.depth;
+                mism = pos >= X.N || d_s(X, pos) != P.at(c);
+                ++c; cur.depth += !mism;
+            }
+        }
+    }
+    have = cnt > 0;
+    if (have && back.start == cur.start && back.end == cur.end && back.depth < cur.depth) back.depth = cur.depth;      // :843-844
+}
+
+// collectIntervals  sparseSA.cpp:968-990 for one prefix whose stack ends in `xmi`: the suffixes of xmi, then (calcMli) for
+// every qualifying stack entry, deepest first, the suffixes LEFT of the entry above it (the reference's second loop runs to
+// xmi.end and is always empty).  The stack is re-derived by a second descent; with EMIT the groups are written back to
+// front so that the deepest comes first, `total` being the count of a previous call.
+template <bool EMIT, class PAT>
+__device__ int collect_intervals(const DIdx& X, const PAT& P, int prefix, IvalD mli, IvalD xmi, bool calcMli, int nextEndStop, int min_len,
+                                 int maxCount, int maxLeft, int total, alfa_match* o) {
+    if (xmi.depth + prefix < min_len) return 0;
+    int cnt = 0;
+    for (int i = xmi.start; i <= xmi.end; ++i) {
+        int64_t mr; int mq, ml;
+        if (lmax_strict(X, P, prefix, (int64_t)X.SA[i], xmi.depth, min_len, maxLeft, mr, mq, ml)) {
+            if (EMIT) { alfa_match m; m.ref = mr; m.query = mq; m.len = ml; o[cnt] = m; }
+            ++cnt;
+        }
+    }
+    if (!calcMli) return cnt;
+    const int K = X.K;
+    const int thr = max(nextEndStop - K, min_len);
+    int tail = total;
+    auto ring = [&](const IvalD& lo, const IvalD& up) {
+        if (!(lo.end - lo.start + 1 <= maxCount / K && prefix + lo.depth > thr)) return;
+        int c = 0;
+        for (int i = lo.start; i < up.start; ++i) {
+            int64_t mr; int mq, ml;
+            if (lmax_strict(X, P, prefix, (int64_t)X.SA[i], lo.depth, min_len, maxLeft, mr, mq, ml)) ++c;
+        }
+        if (EMIT) {
+            tail -= c;
+            int w = 0;
+            for (int i = lo.start; i < up.start; ++i) {
+                int64_t mr; int mq, ml;
+                if (lmax_strict(X, P, prefix, (int64_t)X.SA[i], lo.depth, min_len, maxLeft, mr, mq, ml)) {
+                    alfa_match m; m.ref = mr; m.query = mq; m.len = ml;
+                    o[tail + w++] = m;
+                }
+            }
+        }
+        cnt += c;
+    };
+    bool have; IvalD back;
+    traverse_stack(X, P, prefix, mli, P.len, maxCount, ring, have, back);
+    return cnt;
+}
+
+__global__ __launch_bounds__(SEED_BLOCK) void smemp_count_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
+                                                                int64_t* __restrict__ read_total, WorkRec2* __restrict__ work,
+                                                                int* __restrict__ work_count, int work_cap, int lds_p, int lds_tab,
+                                                                int* g_scratch) {
+    extern __shared__ uint8_t smem[];
+    __shared__ int sh_scan[SEED_BLOCK / 64];
+    const int r = blockIdx.x;
+    const SeedQ Q = qs[r];
+    const int tid = threadIdx.x;
+    PatD P;
+    P.len = Q.plen;
+    const int pbytes = ((Q.plen + 15) & ~15) + 2 * PADB;
+    if (lds_p) {
+        for (int i = tid; i < Q.plen; i += SEED_BLOCK) smem[PADB + i] = reads[Q.poff + i];
+        P.p = smem + PADB;
+    } else {
+        P.p = reads + Q.poff;
+    }
+    const int W = (Q.plen > Q.npref ? Q.plen : Q.npref) + 2;
+    int* tab = lds_tab ? (int*)(smem + (lds_p ? pbytes : 0)) : g_scratch + Q.soff;
+    const int K = X.K;
+    const int sparseQ = Q.sparse_q;
+    const int step = sparseQ * K;
+    const int min_lenK = Q.min_len - (step - 1);
+    const int minMin_len = sparseQ > 1 ? Q.min_len - K : Q.min_len;
+    const int np = Q.npref;
+    __syncthreads();
+    // stage 1: mli of every candidate prefix (:1224)
+    for (int p = tid; p < np; p += SEED_BLOCK) {
+        IvalD mli = {0, X.n - 1, 0};
+        traverse_child(X, P, p, mli.start, mli.end, mli.depth, min_lenK);
+        tab[T_MS * W + p] = mli.start; tab[T_ME * W + p] = mli.end; tab[T_MD * W + p] = mli.depth;
+        tab[T_XD * W + p] = sparseQ > 1 ? -1 : -2;
+    }
+    __syncthreads();
+    if (sparseQ > 1 && tid == 0) {          // the data-dependent skip of :1225,:1252 (as in SMEM)
+        for (int p = 0; p < np; ++p) {
+            tab[T_XD * W + p] = -2;
+            if (tab[T_MD * W + p] <= 1) continue;
+            if (p % K == K - 1) p += (sparseQ - 1) * K;
+        }
+    }
+    __syncthreads();
+    // stage 2: the last stack entry of every visited prefix whose mli reached min_lenK (:1226-1228)
+    for (int p = tid; p < np; p += SEED_BLOCK) {
+        const int md = tab[T_MD * W + p];
+        int xd = -1;
+        if (tab[T_XD * W + p] == -2 && md > 1 && md >= min_lenK) {
+            const IvalD mli = {tab[T_MS * W + p], tab[T_ME * W + p], md};
+            bool have; IvalD back;
+            traverse_stack(X, P, p, mli, Q.plen, Q.max_count, [](const IvalD&, const IvalD&) {}, have, back);
+            if (have) { tab[T_XS * W + p] = back.start; tab[T_XE * W + p] = back.end; xd = back.depth; }
+        }
+        tab[T_XD * W + p] = xd;
+    }
+    __syncthreads();
+    // the running decisions of :1230-1248, in prefix order, on one lane
+    if (tid == 0) {
+        int prevEnd = 0, prevEndPrefix = 0;
+        int64_t prevSize = -1;
+        for (int p = 0; p < np; ++p) {
+            const int xd = tab[T_XD * W + p];
+            if (xd < 0) { tab[T_SEL * W + p] = 0; continue; }
+            const int64_t sz = (int64_t)tab[T_XE * W + p] - tab[T_XS * W + p] + 1;
+            const int end = p + xd;
+            const bool extendXmi = end > prevEnd || prevSize <= Q.max_smem || p <= prevEndPrefix + K || sz <= Q.max_smem;
+            const bool extendMli = extendXmi && sz <= Q.max_smem && (end > prevEnd || prevSize <= Q.max_smem);
+            tab[T_SEL * W + p] = extendXmi ? (extendMli ? 2 : 1) : 0;
+            tab[T_NES * W + p] = prevEnd;
+            if (prevEnd < end) { prevEnd = end; prevSize = sz; prevEndPrefix = prevSize > Q.max_smem ? p : -1; }
+            else { prevSize += sz; if (prevEndPrefix < 0 && prevSize > Q.max_smem) prevEndPrefix = p; }
+        }
+    }
+    __syncthreads();
+    // stage 3: what every selected prefix emits, in prefix order
+    int running = 0;
+    for (int base = 0; base < np; base += SEED_BLOCK) {
+        const int p = base + tid;
+        int cnt = 0, s = 0;
+        IvalD mli = {0, 0, 0}, xmi = {0, 0, 0};
+        if (p < np && (s = tab[T_SEL * W + p]) != 0) {
+            mli = {tab[T_MS * W + p], tab[T_ME * W + p], tab[T_MD * W + p]};
+            xmi = {tab[T_XS * W + p], tab[T_XE * W + p], tab[T_XD * W + p]};
+            cnt = collect_intervals<false>(X, P, p, mli, xmi, s == 2, tab[T_NES * W + p], minMin_len, Q.max_count, step, 0, nullptr);
+        }
+        int total;
+        const int excl = block_excl_scan(cnt, sh_scan, total);
+        const int slot = wave_alloc_slot(work_count, cnt > 0);
+        if (cnt > 0 && slot < work_cap) {
+            WorkRec2 w;
+            w.read = r; w.woff = running + excl; w.prefix = p;
+            w.ms = mli.start; w.me = mli.end; w.md = mli.depth; w.xs = xmi.start; w.xe = xmi.end; w.xd = xmi.depth;
+            w.calc = s == 2; w.nes = tab[T_NES * W + p]; w.nesp = cnt;
+            work[slot] = w;
+        }
+        running += total;
+    }
+    if (tid == 0) read_total[r] = running;
+}
+
 // ---------------------------------------------------------------- MEM / SMEM: emit
 template <int TYPE>
 __global__ void emit2_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads, const int64_t* __restrict__ read_base,
@@ -1089,6 +1286,8 @@ __global__ void emit2_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t
     alfa_match* o = out + read_base[w.read] + w.woff;
     const IvalD mli = {w.ms, w.me, w.md}, xmi = {w.xs, w.xe, w.xd};
     if (TYPE == ALFA_SEED_MEM) collect_mem<true>(X, P, w.prefix, mli, xmi, Q.min_len, step, o);
+    else if (TYPE == ALFA_SEED_SMEMP) collect_intervals<true>(X, P, w.prefix, mli, xmi, w.calc != 0, w.nes, Q.sparse_q > 1 ? Q.min_len - K : Q.min_len,
+                                                              Q.max_count, step, w.nesp /* the count pass's total */, o);
     else collect_xmi_mli<true>(X, P, w.prefix, mli, xmi, w.calc != 0, w.nes, w.nesp, Q.sparse_q > 1 ? Q.min_len - K : Q.min_len,
                                Q.max_count, step, o);
 }
@@ -1332,10 +1531,11 @@ DIdx make_didx(const alfa_index* ix) {
 }
 
 int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, const alfa_seed_query* q, int nq) {
-    if (mem_type != ALFA_SEED_SMAM && mem_type != ALFA_SEED_MEM && mem_type != ALFA_SEED_SMEM)
-        return alfa::fail(ALFA_ENOTSUP, "seed type has no HIP kernel (SMAM, MEM and SMEM do; SMEMP is unreachable from the reference's CLI)");
-    if (!ix->has_child && mem_type == ALFA_SEED_SMEM)
-        return alfa::fail(ALFA_ENOTSUP, "SMEM needs an index with a child table (the reference calls traverse_faster unconditionally)");
+    if (mem_type != ALFA_SEED_SMAM && mem_type != ALFA_SEED_MEM && mem_type != ALFA_SEED_SMEM && mem_type != ALFA_SEED_SMEMP)
+        return alfa::fail(ALFA_EINVAL, "unknown seed type");
+    const bool smem_like = mem_type == ALFA_SEED_SMEM || mem_type == ALFA_SEED_SMEMP;
+    if (!ix->has_child && smem_like)
+        return alfa::fail(ALFA_ENOTSUP, "SMEM / SMEMP need an index with a child table (the reference calls traverse_faster unconditionally)");
 
     pl->ix = ix; pl->nq = nq; pl->launched = false; pl->mem_type = mem_type;
     pl->work_rec = mem_type == ALFA_SEED_SMAM ? sizeof(WorkRec) : sizeof(WorkRec2);
@@ -1367,7 +1567,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
         SeedQ& s = hq[i];
         s.poff = (int64_t)po;
         s.plen = q[i].plen; s.min_len = q[i].min_len; s.max_count = q[i].max_count; s.sparse_q = q[i].sparse_q;
-        const int64_t np = mem_type == ALFA_SEED_SMEM ? count_prefixes_smem(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q)
+        const int64_t np = smem_like ? count_prefixes_smem(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q)
                                                       : count_prefixes(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q);
         if (np < 0 || np > 0x3fffffff) return alfa::fail(ALFA_EINVAL, "seed query has too many prefixes");
         s.npref = (int32_t)np;
@@ -1389,14 +1589,14 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
         s.soff = scr_ints;
         const int w = (int)std::max<int64_t>(q[i].plen, np) + 2;
         max_w = std::max(max_w, w);
-        if (mem_type == ALFA_SEED_SMEM) scr_ints += (int64_t)SMEM_TABLES * w;
+        if (smem_like) scr_ints += (int64_t)SMEM_TABLES * w;
         total_pref += np;
         if (q[i].plen) memcpy(hp + po, q[i].P, (size_t)q[i].plen);
         po += (size_t)q[i].plen;
     }
     pl->total_pref = total_pref;
     pl->max_w = max_w;
-    if (mem_type == ALFA_SEED_SMEM) {
+    if (smem_like) {
         const size_t pbytes = max_plen <= 48 * 1024 ? (((size_t)max_plen + 15) & ~(size_t)15) + 2 * PADB : 0;
         pl->lds_tab = pbytes + (size_t)SMEM_TABLES * 4 * (size_t)max_w + 64 <= 60 * 1024;
         if (!pl->lds_tab && (rc = pl->d_scr.reserve(4 * (size_t)scr_ints + 64))) return rc;
@@ -1471,7 +1671,9 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
     } else {
         const size_t pbytes = lds_p ? (((size_t)pl->max_plen + 15) & ~(size_t)15) + 2 * PADB : 0;
         const size_t lds2 = pbytes + (pl->lds_tab ? (size_t)SMEM_TABLES * 4 * (size_t)pl->max_w : 0) + 16;
-        hipLaunchKernelGGL(smem_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds2, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec2>(), d_cnt,
+        if (pl->mem_type == ALFA_SEED_SMEMP) hipLaunchKernelGGL(smemp_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds2, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec2>(), d_cnt,
+                           pl->seg_cap, lds_p, pl->lds_tab ? 1 : 0, pl->d_scr.as<int>());
+        else hipLaunchKernelGGL(smem_count_kernel, dim3(nq), dim3(SEED_BLOCK), lds2, st, X, d_q, d_reads, d_tot, pl->d_work.as<WorkRec2>(), d_cnt,
                            pl->seg_cap, lds_p, pl->lds_tab ? 1 : 0, pl->d_scr.as<int>());
     }
     ALFA_HIP(hipGetLastError());
@@ -1490,6 +1692,9 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
                            pl->d_out.as<alfa_match>(), pl->out_cap);
     else if (pl->mem_type == ALFA_SEED_MEM)
         hipLaunchKernelGGL(emit2_kernel<ALFA_SEED_MEM>, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec2>(), d_cnt, pl->seg_cap,
+                           pl->d_out.as<alfa_match>(), pl->out_cap);
+    else if (pl->mem_type == ALFA_SEED_SMEMP)
+        hipLaunchKernelGGL(emit2_kernel<ALFA_SEED_SMEMP>, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec2>(), d_cnt, pl->seg_cap,
                            pl->d_out.as<alfa_match>(), pl->out_cap);
     else
         hipLaunchKernelGGL(emit2_kernel<ALFA_SEED_SMEM>, eg, eb, 0, st, X, d_q, d_reads, d_base, nq, pl->d_work.as<WorkRec2>(), d_cnt, pl->seg_cap,

@@ -15,7 +15,7 @@ def test_gpu_seeds_vs_reference_goldens(gpu, K):
         if id(hidx) not in cache:
             cache[id(hidx)] = ffi.DeviceIndex(hidx, gpu)
         return cache[id(hidx)].seed_batch(mt, q)
-    assert G.check_seeds(fn, K, types=(0, 1, 2)) > 300
+    assert G.check_seeds(fn, K, types=(0, 1, 2, 3)) > 300
 
 
 def test_gpu_ksw_vs_captured_mapper_calls(gpu):

@@ -72,7 +72,7 @@ def test_smam_index_without_kmer_table(gpu):
     assert _check(hidx, didx, reads, 30, 1000, 2) > 50
 
 
-@pytest.mark.parametrize("mt", [ffi.SEED_MEM, ffi.SEED_SMEM])
+@pytest.mark.parametrize("mt", [ffi.SEED_MEM, ffi.SEED_SMEM, ffi.SEED_SMEMP])
 @pytest.mark.parametrize("K", [1, 3, 12])
 def test_mem_smem_random_ref(gpu, K, mt):
     rng = np.random.default_rng(200 + K)
@@ -90,7 +90,7 @@ def test_mem_smem_random_ref(gpu, K, mt):
         _check(hidx, didx, reads, 50, 100, 3, mt, max_smem=1)     # sparseQ > 1: data-dependent prefix skipping in SMEM
 
 
-@pytest.mark.parametrize("mt", [ffi.SEED_MEM, ffi.SEED_SMEM])
+@pytest.mark.parametrize("mt", [ffi.SEED_MEM, ffi.SEED_SMEM, ffi.SEED_SMEMP])
 def test_mem_smem_repeats_multi_contig(gpu, mt):
     rng = np.random.default_rng(14)
     a = seqgen.rand_ref(rng, 50000)
@@ -115,7 +115,7 @@ def test_smem_long_reads_use_global_tables(gpu):
     reads = seqgen.sim_reads(rng, ref, 30, 2000, 6000, 0.08)
     ml = [seqgen.seed_params(12, len(r), 0.10)[0] for r in reads]
     sq = [seqgen.seed_params(12, len(r), 0.10)[1] for r in reads]
-    for mt in (ffi.SEED_MEM, ffi.SEED_SMEM):
+    for mt in (ffi.SEED_MEM, ffi.SEED_SMEM, ffi.SEED_SMEMP):
         assert _check(hidx, didx, reads, ml, 10000, sq, mt) > 30
 
 
@@ -151,10 +151,13 @@ def test_smam_suffix_link_index(gpu, K):
     _check(hidx, didx, reads, max(20, K + 10), 100000, 1, ffi.SEED_MEM)
 
 
-def test_unsupported_types_fail_loudly(gpu):
+def test_unsupported_combinations_fail_loudly(gpu):
     rng = np.random.default_rng(5)
     ref = seqgen.rand_ref(rng, 20000)
-    hidx2 = ffi.HostIndex.build_mem(["x"], [ref], K=3)
+    hidx2 = ffi.HostIndex.build_mem(["x"], [ref], K=3, child=False, kmer=False)
     didx2 = ffi.DeviceIndex(hidx2, gpu)
+    for mt in (ffi.SEED_SMEM, ffi.SEED_SMEMP):          # the reference calls traverse_faster (child table) unconditionally there
+        with pytest.raises(ffi.AlfaError):
+            didx2.seed_batch(mt, ffi.make_seed_queries([ref[:100]], 40, 100, 1))
     with pytest.raises(ffi.AlfaError):
-        didx2.seed_batch(ffi.SEED_SMEMP, ffi.make_seed_queries([ref[:100]], 40, 100, 1))
+        didx2.seed_batch(7, ffi.make_seed_queries([ref[:100]], 40, 100, 1))
