@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20000)
     ap.add_argument("--e2e-reads", type=int, default=1000000, help="reads for the end-to-end command line comparison (0 = skip)")
     ap.add_argument("--e2e-threads", type=int, default=16)
+    ap.add_argument("--align-tasks", type=int, default=50000, help="mate-rescue shaped ksw_align tasks for the informative ksw_align section")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for --dist-selftest)")
     ap.add_argument("--dist-selftest", action="store_true", help="CPU rehearsal of the multi-rank control flow, no GPU work")
     args = ap.parse_args()
@@ -366,6 +367,42 @@ def main():
                "sample": "%d reads of the same workload through the compiled reference (oracle/_ref/alfalfa align -t %d), whole command "
                          "line FASTQ -> SAM, %.1f s wall" % (args.e2e_reads, args.e2e_threads, e2e["reference_cpu"]["seconds"]),
                "hot_path_port_1core": port}
+    # ---- ksw_align (mate rescue): not part of `value`; kernel time of one batch of rescue-shaped tasks
+    # (150-bp mate with 3 % substitutions placed in a window of 2-3 mate lengths + 200, the mapper's penalties and xtra)
+    align = None
+    try:
+        arng = np.random.default_rng(4242)
+        nt4 = np.full(256, 4, np.uint8)
+        for i, ch in enumerate(b"acgt"):
+            nt4[ch] = i
+        refc = nt4[np.frombuffer(ref, np.uint8)]
+        pairs = []
+        for _ in range(args.align_tasks):
+            wl = int(arng.integers(2 * 150, 3 * 150 + 200))
+            o = int(arng.integers(0, len(refc) - wl))
+            w = refc[o:o + wl]
+            qo = int(arng.integers(0, wl - 150))
+            qv = w[qo:qo + 150].copy()
+            sub = arng.random(150) < 0.03
+            qv[sub] = (qv[sub] + arng.integers(1, 4, int(sub.sum()))) % 4
+            pairs.append((qv, w))
+        pa = ffi.default_params()
+        pa.gapo, pa.gape = -pa.gapo, -pa.gape          # ksw_align gets alnOptions.openGap / extendGap as they are (negative)
+        xtra = ffi.KSW_XSTART | ffi.KSW_XBYTE
+        atasks, _akeep = ffi.make_align_tasks(pairs, xtra)
+        ffi.ksw_align_batch(pa, atasks)
+        best = min(_align_ms(pa, atasks) for _ in range(3))
+        acells = sum(len(a) * len(b) for a, b in pairs)
+        align = {"tasks": len(pairs), "forward_cells": acells, "kernel_ms": best, "gcups": acells / best / 1e6,
+                 "note": "cells of the forward pass only (the start-position pass runs too); 150-bp mates, byte kernel"}
+        nchk = min(500, len(pairs))
+        sub_t, _k2 = ffi.make_align_tasks(pairs[:nchk], xtra)
+        tt = time.perf_counter()
+        exp = O.orc_ksw_align_batch(pa, sub_t)
+        align["oracle_1core_gcups"] = sum(len(a) * len(b) for a, b in pairs[:nchk]) / (time.perf_counter() - tt) / 1e9
+        align["parity_sample_ok"] = bool(np.array_equal(ffi.ksw_align_batch(pa, sub_t), exp))
+    except Exception as e:  # informative section: never fails the bench line
+        align = {"error": str(e)}
     dp_ms = sum(ext_ms) + sum(nw_ms) + sum(gl_ms)
     out = {
         "metric": "mapped reads/sec (hot path: SMAM seeds both strands + banded DP) + banded-DP GCUPS",
@@ -421,11 +458,18 @@ def main():
                     "concurrently on side streams; the isolated figure is the same launch with the GPU to itself",
         },
         "cpu_baseline": cpu,
+        "ksw_align": align,
         "end_to_end_cli": e2e,
     }
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _align_ms(params, tasks):
+    from alfalfa_amd import ffi
+    ffi.ksw_align_batch(params, tasks)
+    return ffi.last_timing().kernel_ms
 
 
 def C_addr(arr):

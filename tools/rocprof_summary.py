@@ -23,6 +23,36 @@ def dbs(path):
     return sorted(glob.glob(os.path.join(path, "**", "*.db"), recursive=True))
 
 
+def process_command(con):
+    """command line of the profiled process of one rocpd database ('' when the schema does not tell)"""
+    try:
+        names = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
+        for t in names:
+            if t == "processes" or t.startswith("rocpd_info_process"):
+                cols = [r[1] for r in con.execute("pragma table_info('%s')" % t)]
+                for c in ("command", "cmdline", "exe", "name"):
+                    if c in cols:
+                        row = con.execute("select %s from '%s' limit 1" % (c, t)).fetchone()
+                        if row and row[0]:
+                            return str(row[0])
+    except sqlite3.Error:
+        pass
+    return ""
+
+
+def select_dbs(path, only):
+    """rocprofv3 also profiles child processes (bench.py runs the command line tool once to capture its DP tasks): keep the
+    databases whose process command contains `only`, all of them when none does or the schema does not tell"""
+    all_dbs = dbs(path)
+    if not only:
+        return all_dbs
+    keep = [d for d in all_dbs if only in process_command(sqlite3.connect(d))]
+    if not keep:
+        print("note: no database matched --only %r (%d databases used)" % (only, len(all_dbs)), file=sys.stderr)
+        return all_dbs
+    return keep
+
+
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     if "rocprim" in name:
@@ -41,9 +71,9 @@ def short(name):
     return name.strip()
 
 
-def kernels(path, out):
+def kernels(path, out, only=""):
     agg = defaultdict(list)
-    for d in dbs(path):
+    for d in select_dbs(path, only):
         con = sqlite3.connect(d)
         for name, dur in con.execute("select name, duration from kernels"):
             agg[short(name)].append(dur)
@@ -56,9 +86,9 @@ def kernels(path, out):
     return rows
 
 
-def pmc(path, out, jout=None, batch=None, note=""):
+def pmc(path, out, jout=None, batch=None, note="", only=""):
     agg = defaultdict(lambda: defaultdict(list))
-    for d in dbs(path):
+    for d in select_dbs(path, only):
         con = sqlite3.connect(d)
         per = defaultdict(float)
         names = {}
@@ -93,14 +123,15 @@ def main():
     ap.add_argument("--json")
     ap.add_argument("--batch", type=int)
     ap.add_argument("--note", default="")
+    ap.add_argument("--only", default="", help="keep only the databases of processes whose command contains this text")
     a = ap.parse_args()
     if not dbs(a.src):
         sys.exit("no rocprofv3 .db under " + a.src)
     if a.mode == "kernels":
-        for k, v in kernels(a.src, a.out)[:12]:
+        for k, v in kernels(a.src, a.out, a.only)[:12]:
             print("%-60s calls %5d avg %10.1f us" % (k[:60], len(v), sum(v) / len(v) / 1e3))
     else:
-        pmc(a.src, a.out, a.json, a.batch, a.note)
+        pmc(a.src, a.out, a.json, a.batch, a.note, a.only)
         print(open(a.out).read())
 
 
