@@ -1039,6 +1039,11 @@ std::vector<Mapper::PairInfo> Mapper::score_order(const Read& m1, const Read& m2
 void Mapper::paired_match1(Read& m1, Read& m2) {
     unpaired_match(m1);
     unpaired_match(m2);
+    pair_mates1(m1, m2);
+}
+
+// the part of pairedMatch1 behind the two unpairedMatch calls (:1648-1681)
+void Mapper::pair_mates1(Read& m1, Read& m2) {
     const int alnCount1 = (int)m1.alignments.size(), alnCount2 = (int)m2.alignments.size();
     int alnCount = 0;
     const int maxPaired = opt_.alignmentCount + 1;
@@ -1336,6 +1341,12 @@ void Mapper::paired_match45(Read& m1, Read& m2, bool andPair) {
     const int alnCount = std::max(m1.pairedAlignmentCount, m2.pairedAlignmentCount);
     if (popt_.discordant && alnCount < opt_.alignmentCount + 1) discordant_alignments(m1, m2);
 }
+
+// Mode 1 in three steps, for a driver that runs the independent parts of a pair in fibers of their own (the two unpairedMatch
+// calls touch one mate each, and so do the two postprocess calls): same calls, same order per mate, same results.
+void Mapper::map_mate(Read& r) { r.init(); unpaired_match(r); }
+void Mapper::pair_mates(Read& m1, Read& m2) { pair_mates1(m1, m2); }
+void Mapper::finish_mate(Read& r) { postprocess(r, true); }
 
 void Mapper::map_paired(Read& m1, Read& m2) {
     m1.init();

@@ -106,6 +106,11 @@ class Mapper {
     void map_unpaired(Read& read);
     // map_paired: pairedMatch (modes 1..6) + postprocess of both mates (src/main.cpp:179-195)
     void map_paired(Read& m1, Read& m2);
+    // paired mode 1 split into its independent parts: map_mate on each mate, pair_mates on the pair, finish_mate on each mate
+    bool splittable() const { return popt_.mode == 1; }
+    void map_mate(Read& r);
+    void pair_mates(Read& m1, Read& m2);
+    void finish_mate(Read& r);
 
     struct PairInfo { bool first; int pos; int score; };       // alnScoreInfo_t src/mapper.cpp:1512-1518
 
@@ -125,6 +130,7 @@ class Mapper {
     void postprocess(Read& read, bool paired);
     void set_local_pos(Alignment& a);
     void paired_match1(Read& m1, Read& m2);
+    void pair_mates1(Read& m1, Read& m2);
     void paired_match2(Read& m1, Read& m2);
     void paired_match3(Read& m1, Read& m2);
     void paired_match45(Read& m1, Read& m2, bool andPair);

@@ -410,7 +410,14 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 Mapper& mp = *mappers[t];
                 std::string& txt = B.text[t];
                 long* c = &B.cnt[(size_t)t * 4];
-                scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.map_paired(B.a[lo + i], B.b[lo + i]); });
+                if (mp.splittable()) {
+                    // the mates of a pair are independent until they are paired: twice the fibers, half the chain of batch rounds
+                    scheds[t]->run(2 * (hi - lo), o.fibers, [&](int i) { mp.map_mate((i & 1) ? B.b[lo + (i >> 1)] : B.a[lo + (i >> 1)]); });
+                    scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.pair_mates(B.a[lo + i], B.b[lo + i]); });
+                    scheds[t]->run(2 * (hi - lo), o.fibers, [&](int i) { mp.finish_mate((i & 1) ? B.b[lo + (i >> 1)] : B.a[lo + (i >> 1)]); });
+                } else {
+                    scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.map_paired(B.a[lo + i], B.b[lo + i]); });
+                }
                 for (int i = lo; i < hi; i++) {
                     Read& m1 = B.a[i];
                     Read& m2 = B.b[i];

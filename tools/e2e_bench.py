@@ -38,6 +38,25 @@ def write_workload(d, ref_len, n, read_len, err, long_reads, seed=1):
     return fa, fq
 
 
+def write_pairs(d, ref_len, n, seed=1):
+    """n FR pairs of 150-bp mates, fragments of 300-600 bp; a third of the second mates carry a substitution every 14-18
+    bases (no seed of 20+, but alignable without gaps: what --paired-rescue recovers), the others 1-12 % error"""
+    ref = bench.make_reference(ref_len, seed).tobytes()
+    rng = np.random.default_rng(seed + 200)
+
+    def noisy(r):
+        return "periodic" if r.random() < 0.35 else float(r.choice([0.01, 0.03, 0.06, 0.12]))
+    m1, m2 = seqgen.sim_pairs(rng, ref, n, 150, 300, 600, 0.01, noisy, 3000)
+    paths = []
+    for tag, reads in ((1, m1), (2, m2)):
+        path = os.path.join(d, "mates%d.fq" % tag)
+        with open(path, "w") as f:
+            for i, r in enumerate(reads):
+                f.write("@p%d/%d\n%s\n+\n%s\n" % (i, tag, r.decode().upper(), "I" * len(r)))
+        paths.append(path)
+    return paths
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=200000)
@@ -46,12 +65,14 @@ def main():
     ap.add_argument("--read-len", type=int, default=250)
     ap.add_argument("--err", type=float, default=0.02)
     ap.add_argument("--long", action="store_true")
+    ap.add_argument("--paired", action="store_true", help="--reads pairs of 150-bp mates (-1/-2, -I 250 -X 650); add e.g. --extra=--paired-rescue")
     ap.add_argument("--exe", default="gpu,cpu")
     ap.add_argument("--extra", default="")
     ap.add_argument("--dir", default="/tmp/alfa_e2e")
     args = ap.parse_args()
     os.makedirs(args.dir, exist_ok=True)
     fa, fq = write_workload(args.dir, args.ref_len, args.reads, args.read_len, args.err, args.long)
+    mates = write_pairs(args.dir, args.ref_len, args.reads) if args.paired else None
     idx = os.path.join(args.dir, "idx12")
     subprocess.run([EXES["cpu"] if os.path.exists(EXES["cpu"]) else EXES["gpu"], "index", "-r", fa, "-p", idx, "-s", "12"], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -62,7 +83,8 @@ def main():
             print(name, "missing")
             continue
         out = os.path.join(args.dir, "out_%s.sam" % name)
-        cmd = [exe, "align", "-i", idx, "-0", fq, "-o", out, "-t", str(args.threads)] + args.extra.split()
+        inputs = ["-1", mates[0], "-2", mates[1], "-I", "250", "-X", "650"] if args.paired else ["-0", fq]
+        cmd = [exe, "align", "-i", idx] + inputs + ["-o", out, "-t", str(args.threads)] + args.extra.split()
         if name != "ref":
             cmd.append("--stats")
         t0 = time.time()
@@ -72,7 +94,7 @@ def main():
         import hashlib
         body = b"\n".join(l for l in open(out, "rb").read().split(b"\n") if not l.startswith(b"@PG"))
         md5s[name] = hashlib.md5(body).hexdigest()
-        print("%s rc=%d %.2fs %.0f reads/s md5=%s %s" % (name, p.returncode, dt, args.reads / dt, md5s[name], " ".join(stats)), flush=True)
+        print("%s rc=%d %.2fs %.0f reads/s md5=%s %s" % (name, p.returncode, dt, args.reads * (2 if args.paired else 1) / dt, md5s[name], " ".join(stats)), flush=True)
     print("identical:", len(set(md5s.values())) == 1)
 
 
