@@ -312,7 +312,7 @@ def main():
         traffic = None
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # the CPU legs run at N=1 only
         # the oracle (scalar port) on one host core over a bounded sample of the same workload
         nsamp = min(args.cpu_sample, len(fw))
         frac = nsamp / len(fw)
@@ -335,7 +335,7 @@ def main():
     # ---- end-to-end wall clock of the command line tools (FASTQ in -> SAM out, index load included): informative only,
     # never `value`.  The reference executable compiled from /root/reference (oracle/_ref/alfalfa) travels with the tree.
     e2e = None
-    if args.e2e_reads > 0:
+    if args.e2e_reads > 0 and world == 1:
         import hashlib
         import subprocess
         er, _, _, _ = simulate_batch(np.random.default_rng(77), ref, args.e2e_reads, args.read_len, args.err)
@@ -371,6 +371,8 @@ def main():
     # (150-bp mate with 3 % substitutions placed in a window of 2-3 mate lengths + 200, the mapper's penalties and xtra)
     align = None
     try:
+        if world > 1:
+            raise RuntimeError("skipped at N > 1")
         arng = np.random.default_rng(4242)
         nt4 = np.full(256, 4, np.uint8)
         for i, ch in enumerate(b"acgt"):
