@@ -7,7 +7,7 @@
 //
 //   alfa_compat::ksw_extend / ksw_nw / ksw_global   == src/ksw.h:63-106 (ksw_global's CIGAR is malloc'd: free() it)
 //   alfa_compat::ksw_align / kswr_t / KSW_X*        == src/ksw.h:6-19,63 (the query-profile cache argument must be null)
-//   alfa_compat::sparseSA::SMAM / MEM / SMEM        == src/sparseSA.h:274-283 (append to `matches`, never clear it)
+//   alfa_compat::sparseSA::SMAM / MEM / SMEM / SMEMP == src/sparseSA.h:274-283 (append to `matches`, never clear it)
 //   alfa_compat::match_t                            == src/sparseSA.h:103-110
 #pragma once
 #include <cstdlib>
@@ -106,6 +106,9 @@ class sparseSA {
     }
     void SMEM(const std::string& P, std::vector<match_t>& matches, int min_len, int maxCount, int sparseQ, int max_smem_cont) const {
         run(ALFA_SEED_SMEM, P, matches, min_len, maxCount, sparseQ, max_smem_cont);
+    }
+    void SMEMP(const std::string& P, std::vector<match_t>& matches, int min_len, int maxCount, int sparseQ, int max_smem_cont) const {
+        run(ALFA_SEED_SMEMP, P, matches, min_len, maxCount, sparseQ, max_smem_cont);
     }
     const long K;
 

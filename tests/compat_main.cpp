@@ -26,6 +26,7 @@ int main(int argc, char** argv) {
         sa.SMAM(reads[r], m, 20, 1000, 1);
         sa.MEM(reads[r], m, 25, 1000, 1);
         sa.SMEM(reads[r], m, 25, 1000, 1, 10);
+        sa.SMEMP(reads[r], m, 25, 1000, 1, 10);
         printf("R %zu %zu", r, m.size());
         for (auto& x : m) printf(" %ld,%d,%d", x.ref, x.query, x.len);
         printf("\n");

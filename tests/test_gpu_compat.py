@@ -41,7 +41,7 @@ def test_reference_signatures_batch_of_one(gpu):
         r = int(f[1])
         if f[0] == "R":
             exp = [(-7, -7, -7)]
-            for mt, ml, ms in ((ffi.SEED_SMAM, 20, 0), (ffi.SEED_MEM, 25, 0), (ffi.SEED_SMEM, 25, 10)):
+            for mt, ml, ms in ((ffi.SEED_SMAM, 20, 0), (ffi.SEED_MEM, 25, 0), (ffi.SEED_SMEM, 25, 10), (ffi.SEED_SMEMP, 25, 10)):
                 m, off = O.orc_seed_batch(hidx.view, mt, ffi.make_seed_queries([reads[r]], ml, 1000, 1, ms))
                 exp += [(int(x["ref"]), int(x["query"]), int(x["len"])) for x in m]
             got = [tuple(int(v) for v in t.split(",")) for t in f[3:]]
