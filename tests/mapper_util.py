@@ -91,6 +91,13 @@ SYNTH_CONFIGS = {
     "synpe_mode5_rescue": ["-I", "250", "-X", "650", "--paired-rescue", "--paired-mode", "5"],
     "synpe_mode5": ["-I", "250", "-X", "650", "--paired-mode", "5", "-a", "2"],
     "synpe_mode6_rescue": ["-I", "250", "-X", "650", "--paired-rescue", "--paired-mode", "6"],
+    # pairing options (isConcordant :1311, dpWindow :1464, discordant pairs, mixed output)
+    "synpe_rf_rescue": ["-I", "250", "-X", "650", "--paired-rescue", "--orientation", "rf"],
+    "synpe_ff_rescue": ["-I", "250", "-X", "650", "--paired-rescue", "--orientation", "ff"],
+    "synpe_strict_pairs": ["-I", "350", "-X", "500", "--no-mixed", "--no-discordant", "-a", "2"],
+    "synpe_geometry": ["-I", "100", "-X", "450", "--paired-rescue", "--dovetail", "--no-contain", "--no-overlap"],
+    "synpe_mode5_ff": ["-I", "250", "-X", "650", "--paired-rescue", "--paired-mode", "5", "--orientation", "ff", "-a", "3"],
+    "synpe_mode3_rf": ["-I", "250", "-X", "650", "--paired-mode", "3", "--orientation", "rf", "--no-discordant"],
 }
 
 
