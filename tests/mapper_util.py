@@ -142,5 +142,57 @@ def run_synth(exe, name, extra=()):
     return sam_body(out), p.stderr.decode()
 
 
+# ---- synthetic single-end set: the command line options that steer the host logic (src/options.cpp), reference md5s committed
+SYNTH_SE_CONFIGS = {
+    "synse_default": [],
+    "synse_scores": ["-M", "2", "-U", "-3", "-O", "-4", "-E", "-2"],
+    "synse_minlen": ["-l", "25", "-c", "0.1", "-a", "3"],
+    "synse_band_trials": ["-b", "20", "-f", "3", "--reset-failures", "--max-alignments", "50"],
+    "synse_forward_only": ["--no-reverse", "--no-rescue"],
+    "synse_reverse_only": ["--no-forward", "-e", "0.05"],
+    "synse_seeds": ["--no-sparseness", "-m", "50", "--max-smems", "3", "--max-mems", "5", "--min-mem-length", "30", "--seed", "PSMEM"],
+    "synse_mem_local": ["--seed", "MEM", "--local", "-a", "2", "-e", "0.1"],
+    "synse_fulldp": ["--full-dp", "-a", "2"],
+}
+
+
+def synth_single():
+    import numpy as np
+    import seqgen
+    d = workdir()
+    if os.path.exists(os.path.join(d, "synse.fq")):
+        return d
+    rng = np.random.default_rng(4048)
+    a = seqgen.rand_ref(rng, 250000)
+    b = seqgen.rand_ref(rng, 60000)
+    b = b + a[1000:3000] + b"acgt" * 50 + b[:500]            # repeats across and inside contigs
+    with open(os.path.join(d, "synse.fa"), "w") as f:
+        for name, sq in (("ctgA", a), ("ctgB some text", b)):
+            f.write(">%s\n" % name)
+            t = sq.decode().upper()
+            for i in range(0, len(t), 80):
+                f.write(t[i:i + 80] + "\n")
+    cat = a + b"a" * 40 + b
+    reads = seqgen.sim_reads(rng, cat, 2500, 80, 400, 0.03) + seqgen.sim_reads(rng, cat, 150, 800, 3000, 0.08)
+    reads += [seqgen.rand_ref(rng, 150) for _ in range(30)] + [b"acgt" * 40, b"n" * 80, a[1500:1700]]
+    with open(os.path.join(d, "synse.fq"), "w") as f:
+        for i, r in enumerate(reads):
+            f.write("@s%d\n%s\n+\n%s\n" % (i, r.decode().upper(), "5" * len(r)))
+    return d
+
+
+def run_synth_single(exe, name, extra=()):
+    d = synth_single()
+    pre = os.path.join(d, "synse_%s" % os.path.basename(exe))
+    if not os.path.exists(pre + ".aux"):
+        subprocess.run([exe, "index", "-r", "synse.fa", "-p", pre, "-s", "8"], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+    out = os.path.join(d, "out_%s_%s.sam" % (os.path.basename(exe), name))
+    p = subprocess.run([exe, "align", "-i", pre, "-o", out, "-0", "synse.fq"] + SYNTH_SE_CONFIGS[name] + list(extra),
+                       cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return sam_body(out)
+
+
 def synth_md5(name):
     return json.load(open(os.path.join(G.GOLD, "sam_synth_md5.json")))[name]

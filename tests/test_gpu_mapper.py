@@ -27,6 +27,12 @@ def test_gpu_mapper_paired_modes_synthetic(gpu, name):
     assert ("rescue" not in name) or " align 0/0" not in err
 
 
+@pytest.mark.parametrize("name", sorted(M.SYNTH_SE_CONFIGS))
+def test_gpu_mapper_option_sweep_synthetic(gpu, name):
+    """single-end option sweep (scores, seed types, bands, trial limits, strands, --full-dp): md5 of the reference's records"""
+    assert M.md5(M.run_synth_single(M.GPU_EXE, name, ["-t", "4"])) == M.synth_md5(name)
+
+
 def test_gpu_mapper_vs_oracle_mapper_synthetic(gpu):
     """larger synthetic set (two contigs, short + long reads): product binary vs the oracle-backed host mapper"""
     d = M.workdir()

@@ -30,3 +30,10 @@ def test_host_mapper_paired_modes_synthetic(name):
     body, err = M.run_synth(M.CPU_EXE, name, ["-t", "8", "--stats"])
     assert M.md5(body) == M.synth_md5(name)
     assert ("rescue" not in name) or " align 0/0" not in err
+
+
+@pytest.mark.skipif(not os.path.exists(M.CPU_EXE), reason="tests/_cpu_mapper not built")
+@pytest.mark.parametrize("name", sorted(M.SYNTH_SE_CONFIGS))
+def test_host_mapper_option_sweep_synthetic(name):
+    """2 700 synthetic single-end reads (two contigs with repeats, short and long reads): the options that steer the host logic"""
+    assert M.md5(M.run_synth_single(M.CPU_EXE, name, ["-t", "8"])) == M.synth_md5(name)

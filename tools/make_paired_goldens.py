@@ -43,6 +43,10 @@ def main():
         body, _err = M.run_synth(EXE, name, ["-t", "8"])
         synth[name] = hashlib.md5(body).hexdigest()
         print(name, synth[name], len(body))
+    for name in sorted(M.SYNTH_SE_CONFIGS):
+        body = M.run_synth_single(EXE, name, ["-t", "8"])
+        synth[name] = hashlib.md5(body).hexdigest()
+        print(name, synth[name], len(body))
     json.dump(synth, open(os.path.join(G.GOLD, "sam_synth_md5.json"), "w"), indent=1, sort_keys=True)
 
 
