@@ -255,12 +255,11 @@ extern "C" int alfa_ksw_align_batch(const alfa_dp_params* p, const alfa_align_ta
     auto lanes = [&](int k) { return (t[k].xtra & XBYTE) ? 16 : 8; };
     auto lneed = [&](int k) { const int P = lanes(k); return std::max(1, (t[k].qlen + P - 1) / P) * P; };
     const int LDS_MAX = 64 * 1024 - 128;
-    auto bin_of = [&](int k) {          // 0..4: byte kernel Lcap 64..1024, 5..9: 16-bit kernel, 10/11: HBM variants
+    auto bin_of = [&](int k) {          // 0..15: byte kernel, vector capacity 64..1024 in steps of 64; 16..31: 16-bit kernel; 32/33: HBM variants
         const int P = lanes(k), G = 64 / P, L = lneed(k);
-        int c = 0, cap = 64;
-        while (cap < L) cap <<= 1, ++c;
-        if (c > 4 || G * (8 + m) * cap > LDS_MAX) return P == 16 ? 10 : 11;
-        return (P == 16 ? 0 : 5) + c;
+        const int c = (L + 63) / 64 - 1, cap = (c + 1) * 64;
+        if (c > 15 || G * (8 + m) * cap > LDS_MAX) return P == 16 ? 32 : 33;
+        return (P == 16 ? 0 : 16) + c;
     };
     std::vector<int> order(n), bins(n);
     std::iota(order.begin(), order.end(), 0);
@@ -293,11 +292,11 @@ extern "C" int alfa_ksw_align_batch(const alfa_dp_params* p, const alfa_align_ta
         d.boff = (uint32_t)bo;
         if (a.xtra & XSUBO) bo += (size_t)a.tlen / 2 + 1;
         const int b = bins[k], P = lanes(k);
-        if (b >= 10) { d.goff = go; go += (size_t)(8 + m) * ((lneed(k) + 63) / 64 * 64); go = (go + 255) & ~(size_t)255; }
+        if (b >= 32) { d.goff = go; go += (size_t)(8 + m) * ((lneed(k) + 63) / 64 * 64); go = (go + 255) & ~(size_t)255; }
         ht[i] = d;
         if (launches.empty() || bins[order[launches.back().first]] != b) {
             Bin L;
-            L.P = P; L.glob = b >= 10; L.Lcap = b >= 10 ? 0 : 64 << (b % 5); L.first = i; L.count = 0;
+            L.P = P; L.glob = b >= 32; L.Lcap = b >= 32 ? 0 : 64 * (b % 16 + 1); L.first = i; L.count = 0;
             launches.push_back(L);
         }
         launches.back().count++;
