@@ -252,6 +252,7 @@ def main():
     ffi.timer_start(dev)
     for s in range(args.warmup, nsteps):
         run(steps[s])
+    t_enqueue = time.perf_counter() - t0      # host time to issue every launch of the timed steps (no waiting)
     dev_ms = ffi.timer_stop(dev)
     ffi.sync(dev)
     torch.cuda.synchronize()
@@ -430,6 +431,7 @@ def main():
             "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world,
         },
         "device_ms_total": dev_ms,
+        "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
         "dp_gcups": (cells_ext + cells_nw + cells_gl) / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else None,
         "dp_detail": {
             "extend": {"cells": cells_ext, "ms": sum(ext_ms), "gcups": cells_ext / max(sum(ext_ms), 1e-9) / 1e6},
