@@ -2,6 +2,7 @@
 """Turn rocprofv3 output (rocpd sqlite .db files) into the small text summaries committed under profiles/.
 
 usage: rocprof_summary.py kernels <dir-or-db> <out.csv>          per-kernel calls / total / average / min / max / %
+       rocprof_summary.py timeline <dir-or-db> <out.csv>         how the kernels overlap: busy fraction, time alone / shared
        rocprof_summary.py pmc     <dir-or-db> <out.csv> [--json out.json --batch N --note "..."]
                                                                  per-kernel mean of every collected counter per dispatch;
                                                                  the JSON form keeps FETCH_SIZE / WRITE_SIZE as bytes per dispatch
@@ -86,6 +87,63 @@ def kernels(path, out, only=""):
     return rows
 
 
+def timeline(path, out, only=""):
+    """how the kernels of the busiest process share the device: wall span, time with at least one kernel running, and per
+    kernel the time it runs alone / together with others (from the start and end stamps of the kernel trace)"""
+    ev = []
+    for d in select_dbs(path, only):
+        con = sqlite3.connect(d)
+        for name, st, en in con.execute("select name, start, end from kernels"):
+            ev.append((st, en, short(name)))
+    ev.sort()
+    if not ev:
+        return
+    # keep the densest stretch: kernels separated by less than 2 ms of idle device form a cluster (the timed region of the
+    # bench is one: its steps are issued back to back); of the clusters with at least 100 kernels the one with the most kernels per unit of time is analysed
+    clusters, cur, cur_end = [], [], None
+    for e in ev:
+        if cur and e[0] - cur_end > 2000000:
+            clusters.append(cur)
+            cur = []
+        cur.append(e)
+        cur_end = e[1] if cur_end is None or not cur[:-1] else max(cur_end, e[1])
+    clusters.append(cur)
+    big = [c for c in clusters if len(c) >= 100] or clusters
+    best = max(big, key=lambda c: len(c) / max(1, max(e[1] for e in c) - c[0][0]))
+    lo = best[0][0]
+    pts = []
+    for st, en, nm in best:
+        pts.append((st, 1, nm))
+        pts.append((en, -1, nm))
+    pts.sort()
+    active = defaultdict(int)
+    alone = defaultdict(int)
+    shared = defaultdict(int)
+    busy = 0
+    conc_time = defaultdict(int)
+    prev = pts[0][0]
+    for t, dlt, nm in pts:
+        dt = t - prev
+        if dt > 0:
+            live = [k for k, v in active.items() if v > 0]
+            n = sum(active[k] for k in live)
+            if n:
+                busy += dt
+                conc_time[min(n, 8)] += dt
+                for k in live:
+                    (alone if len(live) == 1 else shared)[k] += dt
+        active[nm] += dlt
+        prev = t
+    span = pts[-1][0] - lo
+    with open(out, "w") as f:
+        f.write("# densest stretch of the trace (%d kernels): span %.3f ms, some kernel running %.1f %%\n" % (len(best), span / 1e6, 100.0 * busy / span))
+        f.write("# kernels in flight: " + ", ".join("%d%s: %.1f %%" % (k, "+" if k == 8 else "", 100.0 * v / span) for k, v in sorted(conc_time.items())) + "\n")
+        f.write("kernel,alone_ms,with_others_ms,alone_percent_of_span\n")
+        for k in sorted(set(alone) | set(shared), key=lambda k: -(alone[k] + shared[k])):
+            f.write('"%s",%.3f,%.3f,%.1f\n' % (k, alone[k] / 1e6, shared[k] / 1e6, 100.0 * alone[k] / span))
+    print(open(out).read())
+
+
 def pmc(path, out, jout=None, batch=None, note="", only=""):
     agg = defaultdict(lambda: defaultdict(list))
     for d in select_dbs(path, only):
@@ -117,7 +175,7 @@ def pmc(path, out, jout=None, batch=None, note="", only=""):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["kernels", "pmc"])
+    ap.add_argument("mode", choices=["kernels", "pmc", "timeline"])
     ap.add_argument("src")
     ap.add_argument("out")
     ap.add_argument("--json")
@@ -127,7 +185,9 @@ def main():
     a = ap.parse_args()
     if not dbs(a.src):
         sys.exit("no rocprofv3 .db under " + a.src)
-    if a.mode == "kernels":
+    if a.mode == "timeline":
+        timeline(a.src, a.out, a.only)
+    elif a.mode == "kernels":
         for k, v in kernels(a.src, a.out, a.only)[:12]:
             print("%-60s calls %5d avg %10.1f us" % (k[:60], len(v), sum(v) / len(v) / 1e3))
     else:
