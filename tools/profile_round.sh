@@ -19,7 +19,7 @@ timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INS
 echo "sq done"
 cd "$R"
 python3 tools/rocprof_summary.py kernels "$OUT/kt" gpurun_out/kernel_trace_stats.csv --only bench.py
-python3 tools/rocprof_summary.py timeline "$OUT/kt" gpurun_out/kernel_timeline.csv --only bench.py > /dev/null
+
 python3 tools/rocprof_summary.py pmc "$OUT/fetch" gpurun_out/pmc_fetch_size.csv --json gpurun_out/pmc_traffic.json --batch 100000 --only bench.py \
   --note "bytes per dispatch at 100000 reads/step (C3 workload): raw FETCH_SIZE x 1024 (rocprofv3 reports KiB), rocprofv3 --pmc FETCH_SIZE pass; calibration for this access pattern in r01_fetch_calibration.csv (an isolated 4-16 B gather tallies 64 B; streaming reads tally half their bytes)" > /dev/null
 python3 tools/rocprof_summary.py pmc "$OUT/write" gpurun_out/pmc_write_l2.csv --only bench.py > /dev/null
