@@ -997,7 +997,9 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
     // streams: 0-2 group bins, 3-4 wave bins, 5-7 the LDS backtracks of the group bins
     (void)hipEventRecord(cx->fork_ev, st);
     bool used[alfa::Ctx::NSIDE] = {};
+    static const int side_mod = [] { const char* e = getenv("ALFA_SIDE_STREAMS"); int v = e ? atoi(e) : alfa::Ctx::NSIDE; return v < 1 ? 1 : (v > alfa::Ctx::NSIDE ? alfa::Ctx::NSIDE : v); }();
     auto side = [&](int k) -> hipStream_t {
+        k %= side_mod;
         if (!used[k]) { (void)hipStreamWaitEvent(cx->side[k], cx->fork_ev, 0); used[k] = true; }
         return cx->side[k];
     };

@@ -160,8 +160,8 @@ def dist_selftest(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=100000, help="reads per step per GPU")
     ap.add_argument("--ref-len", type=int, default=5000000)
     ap.add_argument("--read-len", type=int, default=250)
