@@ -447,6 +447,16 @@ struct PrefixMap {
         }
         return k + jj * step;
     }
+    // the same without a divergent branch (selects): the filter stage runs it for every query
+    __device__ __forceinline__ int prefix_of_select(int t) const {
+        const int split = kh * nh;
+        const bool first = t < split;
+        const int tt = first ? t : t - split;
+        const uint32_t mm = first ? m1 : m2;
+        const int nn = first ? nh : nh - 1;
+        const int q = mm ? (int)__umulhi((uint32_t)tt, mm) : tt;
+        return (first ? q : kh + q) + (tt - q * nn) * step;
+    }
 };
 
 // block-wide exclusive scan of one int per thread (SEED_BLOCK threads); total returned to every thread
@@ -697,6 +707,20 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
         int qn = 0, base = 0;
         for (;;) {
             // ---- stage 1
+            // common case (read in LDS, 10-mer table): straight-line code, no divergent branch
+            while (in_lds && use_kmer && qn < 64 && base < Q.npref) {
+                const int t = base + lane;
+                const bool valid = t < Q.npref;
+                const int pf = pm.prefix_of_select(valid ? t : 0);
+                const uint32_t packed = kmer_code_packed(codes, min(pf, Q.plen));
+                const uint32_t index = pf + KMER <= Q.plen ? packed : 0xFFFFFFFFu;
+                const uint32_t ix = index < TABLE ? index : 0u;
+                const bool keep = valid && index < TABLE && ((bits[ix >> 5] >> (ix & 31)) & 1u);
+                const uint64_t m = __ballot(keep);
+                if (keep) wq[qn + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)pf, index);
+                qn += __popcll(m);
+                base += 64;
+            }
             while (qn < 64 && base < Q.npref) {
                 const int t = base + lane;
                 bool keep = t < Q.npref;
