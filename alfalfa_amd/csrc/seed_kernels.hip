@@ -96,6 +96,21 @@ __device__ __forceinline__ uint32_t bitadd(uint32_t c) {
     return c == 'a' ? 0u : c == 'c' ? 1u : c == 'g' ? 2u : c == 't' ? 3u : 0xFFFFFFFFu;
 }
 
+// bitadd of four residues at once: byte k of the result is the 2-bit code of byte k of `w`, with 0x80 set when that byte is
+// not one of acgtACGT or when k >= nvalid (positions behind the read)
+__device__ __forceinline__ uint32_t codes_of4(uint32_t w, int nvalid) {
+    const uint32_t x = w | 0x20202020u;
+    auto eq = [&](uint32_t letter) {            // 0x80 in every byte of x that equals `letter`, exact per byte
+        const uint32_t t = x ^ (letter * 0x01010101u);
+        return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;
+    };
+    const uint32_t za = eq('a'), zc = eq('c'), zg = eq('g'), zt = eq('t');
+    const uint32_t code = (zc >> 7) | (zg >> 6) | (zt >> 7) | (zt >> 6);
+    const uint32_t other = ~(za | zc | zg | zt) & 0x80808080u;
+    const uint32_t behind = nvalid >= 4 ? 0u : (nvalid <= 0 ? 0x80808080u : 0x80808080u << (8 * nvalid));
+    return code | other | behind;
+}
+
 __device__ __forceinline__ int d_child(const DIdx& X, int i) { return (i >= 0 && i < X.n) ? X.CHILD[i] : -1; }
 
 // vec_uchar::operator[] (sparseSA.h:79-84)
@@ -676,18 +691,16 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
         const SeedQ Q = qs[r];
         PatD P;
         P.len = Q.plen;
-        const bool in_lds = Q.plen + 2 * PADB <= lds_stride;
+        const bool in_lds = Q.plen + 2 * PADB + 8 <= lds_stride;        // + 8: the staging loop writes whole 8-byte words
         uint8_t* codes = mybuf + lds_stride;                    // second half of the wave's slice: one 2-bit code per residue
         if (in_lds) {
-            for (int i = lane; i < Q.plen + 16; i += 64) {
-                uint32_t cd = 0x80u;
-                if (i < Q.plen) {
-                    const uint32_t ch = reads[Q.poff + i];
-                    mybuf[PADB + i] = (uint8_t)ch;
-                    const uint32_t b = bitadd(ch);
-                    cd = b > 3u ? 0x80u : b;
-                }
-                codes[i] = (uint8_t)cd;
+            // eight residues per lane and trip (one 250-bp read = one trip): the bytes, and their 2-bit codes computed on four
+            // bytes at a time (0x80 set for anything but acgt/ACGT and for positions behind the read)
+            for (int off = 8 * lane; off < Q.plen + 16; off += 512) {
+                const uint64_t v = ld8(reads + Q.poff + off);
+                *(uint64_t*)(mybuf + PADB + off) = v;
+                const uint32_t c0 = codes_of4((uint32_t)v, Q.plen - off), c1 = codes_of4((uint32_t)(v >> 32), Q.plen - off - 4);
+                *(uint64_t*)(codes + off) = (uint64_t)c0 | ((uint64_t)c1 << 32);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1641,7 +1654,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
         }
         pl->nseg = std::max(1, std::min(ncu, (nq + PWAVES - 1) / PWAVES));
         const int room = ((160 * 1024 - KBIT_BYTES - 1024) / PWAVES - WQ_BYTES) / 2;      // LDS bytes a wave can have for its read (x2: codes)
-        pl->stride = std::min(room & ~15, (max_plen + 2 * PADB + 15) & ~15);              // longer reads are read from global memory
+        pl->stride = std::min(room & ~15, (max_plen + 2 * PADB + 8 + 15) & ~15);              // longer reads are read from global memory
         if ((rc = pl->d_q3.reserve(sizeof(Q3) * (size_t)pl->nseg * PWAVES * Q3_CAP + 64))) return rc;
     }
     const int64_t total_cap = std::min<int64_t>(std::max<int64_t>(4096, 4 * (int64_t)nq), std::max<int64_t>(total_pref, 1));
