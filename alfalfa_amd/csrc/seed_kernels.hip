@@ -687,8 +687,19 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
         }
     };
 
-    for (int r = blockIdx.x * PWAVES + wid; r < nq; r += gridDim.x * PWAVES) {      // wave-uniform
-        const SeedQ Q = qs[r];
+    // The descriptor of a read and the first 512 bytes of its text are fetched one read ahead (the descriptor two ahead, so
+    // that the text address is known when its load is issued): both latencies hide behind the work on the current read.
+    const int rstride = gridDim.x * PWAVES;
+    const int r0 = blockIdx.x * PWAVES + wid;
+    SeedQ Qcur = qs[r0 < nq ? r0 : 0];
+    SeedQ Qnext = qs[r0 + rstride < nq ? r0 + rstride : 0];
+    uint64_t vcur = (r0 < nq && 8 * lane < Qcur.plen + 16) ? ld8(reads + Qcur.poff + 8 * lane) : 0ull;
+    for (int r = r0; r < nq; r += rstride) {      // wave-uniform
+        const SeedQ Q = Qcur;
+        const uint64_t vfirst = vcur;
+        Qcur = Qnext;
+        if (r + rstride < nq && 8 * lane < Qcur.plen + 16) vcur = ld8(reads + Qcur.poff + 8 * lane);
+        Qnext = qs[r + 2 * rstride < nq ? r + 2 * rstride : 0];
         PatD P;
         P.len = Q.plen;
         const bool in_lds = Q.plen + 2 * PADB + 8 <= lds_stride;        // + 8: the staging loop writes whole 8-byte words
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
             // eight residues per lane and trip (one 250-bp read = one trip): the bytes, and their 2-bit codes computed on four
             // bytes at a time (0x80 set for anything but acgt/ACGT and for positions behind the read)
             for (int off = 8 * lane; off < Q.plen + 16; off += 512) {
-                const uint64_t v = ld8(reads + Q.poff + off);
+                const uint64_t v = off < 512 ? vfirst : ld8(reads + Q.poff + off);
                 *(uint64_t*)(mybuf + PADB + off) = v;
                 const uint32_t c0 = codes_of4((uint32_t)v, Q.plen - off), c1 = codes_of4((uint32_t)(v >> 32), Q.plen - off - 4);
                 *(uint64_t*)(codes + off) = (uint64_t)c0 | ((uint64_t)c1 << 32);
