@@ -328,8 +328,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
 // layout and exact max-plus scan as above with C = 1, 2 or 4 diagonals per lane (bands up to 16, 32, 64 diagonals) -- so
 // one instruction stream advances four tasks, and every cross-lane step stays inside a row (row_shr / row_shl / row_ror).
 // What was wave-uniform above (band limits, maxima, the Z-drop exit) is row-uniform here and kept per lane.
-constexpr int GL = 16;                // lanes per task
-constexpr int GPW = 64 / GL;          // tasks per wavefront
+constexpr int GL16 = 16;              // lanes per task of the 16-lane form: the direction rows hold 16 x C bytes either way
 
 __device__ __forceinline__ int row_excl_max_scan(int v, int identity) {
     constexpr int NEG = (int)0x80000000;
@@ -347,11 +346,40 @@ __device__ __forceinline__ int row_max(int v) {
     v = max(v, dpp<0x121, 0xf>(v, v));
     return v;
 }
-__device__ __forceinline__ int row_min(int v) { return -row_max(-v); }
 // lane i <- lane i+1 of its row; the row's last lane <- fill
 __device__ __forceinline__ int row_shift_down1(int v, int fill) { return dpp<0x101, 0xf>(fill, v); }
 
-template <int MODE, int C>
+// The same three primitives for a task group of G = 16 lanes (a DPP row) or 8 lanes (half a row; gl = lane within the group).
+// Half rows: the shifts cross the middle of the row and are masked per lane; the maximum is a butterfly of two quad
+// permutations and the half-row mirror.
+template <int G>
+__device__ __forceinline__ int grp_excl_max_scan(int v, int identity, int gl) {
+    if (G == 16) return row_excl_max_scan(v, identity);
+    constexpr int NEG = (int)0x80000000;
+    int t;
+    t = dpp<0x111, 0xf>(NEG, v); v = max(v, gl >= 1 ? t : NEG);
+    t = dpp<0x112, 0xf>(NEG, v); v = max(v, gl >= 2 ? t : NEG);
+    t = dpp<0x114, 0xf>(NEG, v); v = max(v, gl >= 4 ? t : NEG);
+    t = dpp<0x111, 0xf>(identity, v);
+    return gl >= 1 ? t : identity;
+}
+template <int G>
+__device__ __forceinline__ int grp_max(int v) {
+    if (G == 16) return row_max(v);
+    v = max(v, dpp<0xB1, 0xf>(v, v));       // quad_perm [1,0,3,2]
+    v = max(v, dpp<0x4E, 0xf>(v, v));       // quad_perm [2,3,0,1]
+    v = max(v, dpp<0x141, 0xf>(v, v));      // row_half_mirror
+    return v;
+}
+template <int G>
+__device__ __forceinline__ int grp_min(int v) { return -grp_max<G>(-v); }
+template <int G>
+__device__ __forceinline__ int grp_shift_down1(int v, int fill, int gl) {
+    const int t = row_shift_down1(v, fill);
+    return (G == 16 || gl != G - 1) ? t : fill;
+}
+
+template <int MODE, int C, int GL>
 __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __restrict__ tasks, int ntask,
                                                             const uint8_t* __restrict__ seq,
                                                             const DevParams* __restrict__ prm,
@@ -361,7 +389,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
     __syncthreads();
     const int lane = lane_id();
     const int gl = lane & (GL - 1);
-    const int task = (blockIdx.x * WPB + (threadIdx.x >> 6)) * GPW + (lane >> 4);
+    const int task = (blockIdx.x * WPB + (threadIdx.x >> 6)) * (64 / GL) + lane / GL;
     const bool valid = task < ntask;
     const DevTask T = tasks[valid ? task : ntask - 1];
     const uint8_t* __restrict__ q = seq + T.qoff;
@@ -400,8 +428,9 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
     int beg = 0, end = qlen;
     int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
     bool done = false;
-    // rows run to the longest of the wave's four targets
+    // rows run to the longest of the wave's targets
     int tmax = tlen;
+    if (GL == 8) tmax = max(tmax, __shfl_xor(tmax, 8, 64));
     tmax = max(tmax, __shfl_xor(tmax, 16, 64));
     tmax = max(tmax, __shfl_xor(tmax, 32, 64));
     uint32_t tnext = tlen > 0 ? tg[0] : 0u;           // target residue of row i, fetched one row ahead
@@ -445,11 +474,11 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
 #pragma unroll
         for (int c = 1; c < C; ++c) L = max(L - gape, Bv[c]);
         const int Cg = C * gape;
-        const int gx = row_excl_max_scan(L + gl * Cg, 0);
+        const int gx = grp_excl_max_scan<GL>(L + gl * Cg, 0, gl);
         int f = gl == 0 ? FLOOR : gx - (gl - 1) * Cg;
 
         int Hrow[C], Eo[C];
-        uint32_t zpack = 0;
+        uint64_t zpack = 0;
         int m_l = -1, mj_l = -1;
         int zl_l = -1, zr_l = 0x7fffffff;
 #pragma unroll
@@ -467,7 +496,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
             if (MODE == MODE_GLOBAL) {
                 dd |= (e2 > t) ? 4u : 0u;
                 dd |= (f2 > t) ? 32u : 0u;
-                zpack |= (act[c] ? dd : 0u) << (8 * c);
+                zpack |= (uint64_t)(act[c] ? dd : 0u) << (8 * c);
             }
             Eo[c] = act[c] ? (e2 > t ? e2 : t) : (live ? FLOOR : E[c]);
             const int tt = act[c] ? t : FLOOR;
@@ -479,14 +508,15 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
         }
         if (MODE == MODE_GLOBAL && live) {
             uint8_t* zr = zbuf + T.zoff + (int64_t)i * ROWB + gl * C;
-            if (C == 4) *(uint32_t*)zr = zpack;
+            if (C == 8) *(uint64_t*)zr = zpack;
+            else if (C == 4) *(uint32_t*)zr = (uint32_t)zpack;
             else if (C == 2) *(uint16_t*)zr = (uint16_t)zpack;
             else *zr = (uint8_t)zpack;
         }
 
         if (MODE == MODE_EXTEND) {
-            const int m = row_max(m_l);
-            const int mj = row_max(m_l == m ? mj_l : -1);
+            const int m = grp_max<GL>(m_l);
+            const int mj = grp_max<GL>(m_l == m ? mj_l : -1);
             const bool empty = !(beg < end);
             const int jfin = empty ? beg : end;
             int h1 = h0 - (gapo + gape * (i + 1));
@@ -498,7 +528,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
                 int hv = -1;
 #pragma unroll
                 for (int c = 0; c < C; ++c) hv = (gl * C + c == dl) ? Hrow[c] : hv;
-                h1 = row_max(hv);
+                h1 = grp_max<GL>(hv);
             }
             int zl = -1, zr = 0x7fffffff;
 #pragma unroll
@@ -510,8 +540,8 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
                     if (j >= mjrow_l + 1 && j < zr_l) zr_l = j;
                 }
             }
-            zl = row_max(zl_l);
-            zr = row_min(zr_l);
+            zl = grp_max<GL>(zl_l);
+            zr = grp_min<GL>(zr_l);
             if (live) {
                 if (jfin == qlen) {
                     max_ie = gscore > h1 ? max_ie : i;
@@ -553,8 +583,8 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
 
         // shift E and the query characters one diagonal down for the next row (rows that are over keep their state)
         {
-            const int e_up = row_shift_down1(Eo[0], FLOOR);
-            const uint32_t q_up = (uint32_t)row_shift_down1((int)qc[0], (int)qfeed);
+            const int e_up = grp_shift_down1<GL>(Eo[0], FLOOR, gl);
+            const uint32_t q_up = (uint32_t)grp_shift_down1<GL>((int)qc[0], (int)qfeed, gl);
             if (live) {
 #pragma unroll
                 for (int c = 0; c < C - 1; ++c) { E[c] = Eo[c + 1]; qc[c] = qc[c + 1]; }
@@ -577,7 +607,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
         int hv = (int)0x80000000;
 #pragma unroll
         for (int c = 0; c < C; ++c) hv = (gl * C + c == dl) ? Hd[c] : hv;
-        const int score = (dl >= 0 && dl <= 2 * w) ? row_max(hv) : NEG_INF;
+        const int score = (dl >= 0 && dl <= 2 * w) ? grp_max<GL>(hv) : NEG_INF;
         if (gl == 0) out[T.orig] = score;
     }
 }
@@ -953,12 +983,23 @@ void launch_wave(hipStream_t st, const DevTask* d_tasks, int n, const uint8_t* d
     hipLaunchKernelGGL((ksw_wave_kernel<MODE, C>), grid, block, 0, st, d_tasks, n, d_seq, d_prm, d_out, d_z);
 }
 
+// a band class of 16 x C diagonals runs as 16 lanes x C diagonals (4 tasks per wavefront) or, with ALFA_DP_GROUP8 set, as 8 lanes
+// x 2C diagonals (8 tasks per wavefront, same direction-byte layout).  Measured on the C3 task stream the 8-lane form is 7-15 %
+// slower (extend 142 vs 153, nw 296 vs 347, global 66 vs 75 GCUPS): the cell work per lane doubles and the masked half-row
+// shifts cost more than sharing the per-row reductions saves; it stays as a parity-tested A/B switch.
 template <int MODE, int C>
 void launch_group(hipStream_t st, const DevTask* d_tasks, int n, const uint8_t* d_seq, const DevParams* d_prm, int32_t* d_out, uint8_t* d_z) {
     if (n <= 0) return;
-    const int per_block = WPB * GPW;
-    hipLaunchKernelGGL((ksw_group_kernel<MODE, C>), dim3((n + per_block - 1) / per_block), dim3(64 * WPB), 0, st, d_tasks, n, d_seq, d_prm,
-                       d_out, d_z);
+    static const bool half_rows = getenv("ALFA_DP_GROUP8") != nullptr;
+    if (!half_rows) {
+        const int per_block = WPB * 4;
+        hipLaunchKernelGGL((ksw_group_kernel<MODE, C, 16>), dim3((n + per_block - 1) / per_block), dim3(64 * WPB), 0, st, d_tasks, n, d_seq, d_prm,
+                           d_out, d_z);
+    } else {
+        const int per_block = WPB * 8;
+        hipLaunchKernelGGL((ksw_group_kernel<MODE, 2 * C, 8>), dim3((n + per_block - 1) / per_block), dim3(64 * WPB), 0, st, d_tasks, n, d_seq, d_prm,
+                           d_out, d_z);
+    }
 }
 
 template <int MODE>
@@ -1004,7 +1045,7 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
         return cx->side[k];
     };
     for (int g = 0; g < 3; ++g) {
-        const int n = bc[3 + g], nbig = b->nbig[g], rowb = GL << g;
+        const int n = bc[3 + g], nbig = b->nbig[g], rowb = GL16 << g;
         if (n > 0) {
             hipStream_t s2 = side(g);
             if (g == 0) launch_group<MODE, 1>(s2, d_t + o, n, d_seq, d_prm, d_out, d_z);
@@ -1081,7 +1122,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         else { const int W = 2 * w_eff[i] + 1; bin = W <= 16 ? 3 : W <= 32 ? 4 : W <= 64 ? 5 : W <= 128 ? 6 : W <= 256 ? 7 : 8; }
         bins[i] = bin;
         b->bin_cnt[bin]++;
-        if (bin >= 3 && bin <= 5 && (int64_t)x.tlen * (GL << (bin - 3)) > ZC) b->nbig[bin - 3]++;
+        if (bin >= 3 && bin <= 5 && (int64_t)x.tlen * (GL16 << (bin - 3)) > ZC) b->nbig[bin - 3]++;
         if (bin >= 3 && bin <= 5 && x.tlen >= LONG_TLEN) b->nlong[bin - 3]++;
         seq_bytes += (size_t)x.qlen + (size_t)x.tlen;
     }
@@ -1107,7 +1148,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
     DevTask* ht = (DevTask*)(hprm + 1);
     *hprm = b->hp;
     size_t so = 0;
-    const int rowb[9] = {0, 0, 0, GL * 1, GL * 2, GL * 4, 64 * 2, 64 * 4, 0};     // direction bytes per row
+    const int rowb[9] = {0, 0, 0, GL16 * 1, GL16 * 2, GL16 * 4, 64 * 2, 64 * 4, 0};     // direction bytes per row
     const int m = b->hp.m;
     int bin_start[10] = {0};
     for (int k = 0; k < 9; ++k) bin_start[k + 1] = bin_start[k] + b->bin_cnt[k];
