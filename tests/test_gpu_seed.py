@@ -161,3 +161,28 @@ def test_unsupported_combinations_fail_loudly(gpu):
             didx2.seed_batch(mt, ffi.make_seed_queries([ref[:100]], 40, 100, 1))
     with pytest.raises(ffi.AlfaError):
         didx2.seed_batch(7, ffi.make_seed_queries([ref[:100]], 40, 100, 1))
+
+
+def test_smam_read_bytes_of_every_kind(gpu):
+    """the persistent kernel derives 2-bit codes four read bytes at a time: upper / lower case, IUPAC letters, punctuation and
+    bytes >= 0x80 anywhere in a read must behave as in bitadd (src/sparseSA.h:38-63): only acgtACGT are residues"""
+    rng = np.random.default_rng(77)
+    ref = seqgen.rand_ref(rng, 200000)
+    hidx = ffi.HostIndex.build_mem(["x"], [ref], K=12)
+    didx = ffi.DeviceIndex(hidx, gpu)
+    base = seqgen.sim_reads(rng, ref, 300, 90, 300, 0.01)
+    odd = b"nNrRyY-*.@`{AaCcGgTt\x01\x7f\x80\xc1\xe3\xff5 "
+    reads = []
+    for k, r in enumerate(base):
+        b = bytearray(r.upper() if k % 3 == 0 else r)
+        if k % 2:
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(0, len(b)))] = odd[int(rng.integers(0, len(odd)))]
+        if k % 5 == 0:
+            for i in range(0, len(b), 2):
+                b[i] = bytes([b[i]]).swapcase()[0] if bytes([b[i]]).isalpha() else b[i]
+        reads.append(bytes(b))
+    for plen in (9, 10, 11, 15, 16, 17, 23, 24, 25, 63, 64, 65):      # lengths around the 8-byte staging words
+        reads.append(bytes(ref[1000:1000 + plen]))
+    assert _check(hidx, didx, reads, 20, 10000, 1) > 150
+    _check(hidx, didx, reads, 40, 10000, 2)
