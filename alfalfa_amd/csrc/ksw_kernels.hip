@@ -338,6 +338,17 @@ __device__ __forceinline__ int row_excl_max_scan(int v, int identity) {
     v = max(v, dpp<0x118, 0xf>(NEG, v));
     return dpp<0x111, 0xf>(identity, v);
 }
+// the same for values >= 0 with identity 0 (ksw_extend: every H, E, F is clamped at 0): lanes shifted in from outside the row
+// read 0 (bound_ctrl), which lets the compiler fuse every step into one v_max_i32_dpp
+template <int CTRL>
+__device__ __forceinline__ int dpp_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int row_excl_max_scan_nonneg(int v) {
+    v = max(v, dpp_zero<0x111>(v));
+    v = max(v, dpp_zero<0x112>(v));
+    v = max(v, dpp_zero<0x114>(v));
+    v = max(v, dpp_zero<0x118>(v));
+    return dpp_zero<0x111>(v);
+}
 // maximum over the 16 lanes of the row, in every lane (rotations: max is idempotent)
 __device__ __forceinline__ int row_max(int v) {
     v = max(v, dpp<0x128, 0xf>(v, v));
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
 #pragma unroll
         for (int c = 1; c < C; ++c) L = max(L - gape, Bv[c]);
         const int Cg = C * gape;
-        const int gx = grp_excl_max_scan<GL>(L + gl * Cg, 0, gl);
+        const int gx = (MODE == MODE_EXTEND && GL == 16) ? row_excl_max_scan_nonneg(L + gl * Cg) : grp_excl_max_scan<GL>(L + gl * Cg, 0, gl);
         int f = gl == 0 ? FLOOR : gx - (gl - 1) * Cg;
 
         int Hrow[C], Eo[C];
