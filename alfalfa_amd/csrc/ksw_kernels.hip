@@ -351,10 +351,13 @@ __device__ __forceinline__ int row_excl_max_scan_nonneg(int v) {
 }
 // maximum over the 16 lanes of the row, in every lane (rotations: max is idempotent)
 __device__ __forceinline__ int row_max(int v) {
-    v = max(v, dpp<0x128, 0xf>(v, v));
-    v = max(v, dpp<0x124, 0xf>(v, v));
-    v = max(v, dpp<0x122, 0xf>(v, v));
-    v = max(v, dpp<0x121, 0xf>(v, v));
+    // every lane of a rotation has a source, so `old` is never used: the identity of max there lets each step fuse into one
+    // v_max_i32_dpp (with old = v the compiler keeps a separate v_mov_b32_dpp)
+    constexpr int NEG = (int)0x80000000;
+    v = max(v, dpp<0x128, 0xf>(NEG, v));
+    v = max(v, dpp<0x124, 0xf>(NEG, v));
+    v = max(v, dpp<0x122, 0xf>(NEG, v));
+    v = max(v, dpp<0x121, 0xf>(NEG, v));
     return v;
 }
 // lane i <- lane i+1 of its row; the row's last lane <- fill
