@@ -43,7 +43,8 @@ struct AParams {
 
 struct PassOut { int score, te, qe, score2, te2; };
 
-__device__ __forceinline__ int subs(int a, int b) { return max(a - b, 0); }                        // _mm_subs_epu8 / _mm_subs_epu16
+// _mm_subs_epu8 / _mm_subs_epu16 on values that are all in [0, 65535]: one v_sub_u32 with the clamp bit
+__device__ __forceinline__ int subs(int a, int b) { return (int)__builtin_elementwise_sub_sat((unsigned)a, (unsigned)b); }
 __device__ __forceinline__ int lane_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); }   // row_shr:1
 
 template <int P>
@@ -91,7 +92,7 @@ __device__ __forceinline__ PassOut striped_pass(const AParams& pr, const int8_t*
             int h = k > 0 && slen > 0 ? HB[oPrev + (slen - 1) * P + k - 1] : 0;                                 // :141-142
             for (int j = 0; j < slen; ++j) {                                                        // :143-167
                 const int x = j * P + k;
-                if (P == 16) h = max(min(h + (int)S[x], 255) - shift, 0);                           // adds_epu8 then subs_epu8
+                if (P == 16) h = subs(min(h + (int)S[x], 255), shift);                              // adds_epu8 then subs_epu8
                 else h = h + (int)(int8_t)S[x];                                                     // adds_epi16 (cannot saturate: host check)
                 int e = E[x];
                 h = max(max(h, e), f);
