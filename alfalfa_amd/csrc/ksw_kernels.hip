@@ -93,6 +93,9 @@ __device__ __forceinline__ int lane_bcast(int v, int src) { return __builtin_amd
 // lane i <- lane i+1; lane 63 <- fill
 __device__ __forceinline__ int wave_shift_down1(int v, int fill) { return dpp<0x130, 0xf>(fill, v); }
 
+// max(a - b, 0) for 0 <= a, b: one v_sub_u32 with the clamp bit
+__device__ __forceinline__ int sub_floor0(int a, int b) { return (int)__builtin_elementwise_sub_sat((unsigned)a, (unsigned)b); }
+
 __device__ __forceinline__ int score_of(uint64_t mr, uint32_t q) { return (int)(int8_t)(mr >> (8 * q)); }
 
 // ---------------------------------------------------------------- wave-per-task kernel
@@ -174,8 +177,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
             const int e = E[c];
             if (MODE == MODE_EXTEND) { A[c] = hh > e ? hh : e; dirH[c] = 0; }
             else { dirH[c] = hh >= e ? 0u : 1u; A[c] = hh >= e ? hh : e; }
-            int bv = A[c] - gapoe;
-            if (MODE == MODE_EXTEND) bv = bv > 0 ? bv : 0;
+            const int bv = MODE == MODE_EXTEND ? sub_floor0(A[c], gapoe) : A[c] - gapoe;      // ksw_extend clamps at 0 (A >= 0 there)
             Bv[c] = act[c] ? bv : FLOOR;
         }
         // lane-local contribution to the F chain, then the cross-lane max-plus scan
@@ -198,8 +200,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
             if (MODE == MODE_EXTEND) { h = h > F ? h : F; }
             else { if (!(h >= F)) { dd = 2u; h = F; } }
             Hrow[c] = h;
-            int t = h - gapoe;
-            if (MODE == MODE_EXTEND) t = t > 0 ? t : 0;
+            const int t = MODE == MODE_EXTEND ? sub_floor0(h, gapoe) : h - gapoe;
             const int e2 = E[c] - gape;
             const int f2 = F - gape;
             if (MODE == MODE_GLOBAL) {
@@ -480,8 +481,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
             const int e = E[c];
             if (MODE == MODE_EXTEND) { A[c] = hh > e ? hh : e; dirH[c] = 0; }
             else { dirH[c] = hh >= e ? 0u : 1u; A[c] = hh >= e ? hh : e; }
-            int bv = A[c] - gapoe;
-            if (MODE == MODE_EXTEND) bv = bv > 0 ? bv : 0;
+            const int bv = MODE == MODE_EXTEND ? sub_floor0(A[c], gapoe) : A[c] - gapoe;      // ksw_extend clamps at 0 (A >= 0 there)
             Bv[c] = act[c] ? bv : FLOOR;
         }
         int L = Bv[0];
@@ -503,8 +503,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
             if (MODE == MODE_EXTEND) { h = h > F ? h : F; }
             else { if (!(h >= F)) { dd = 2u; h = F; } }
             Hrow[c] = h;
-            int t = h - gapoe;
-            if (MODE == MODE_EXTEND) t = t > 0 ? t : 0;
+            const int t = MODE == MODE_EXTEND ? sub_floor0(h, gapoe) : h - gapoe;
             const int e2 = E[c] - gape;
             const int f2 = F - gape;
             if (MODE == MODE_GLOBAL) {
