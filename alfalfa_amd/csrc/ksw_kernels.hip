@@ -97,6 +97,8 @@ __device__ __forceinline__ int wave_shift_down1(int v, int fill) { return dpp<0x
 __device__ __forceinline__ int sub_floor0(int a, int b) { return (int)__builtin_elementwise_sub_sat((unsigned)a, (unsigned)b); }
 
 __device__ __forceinline__ int score_of(uint64_t mr, uint32_t q) { return (int)(int8_t)(mr >> (8 * q)); }
+// the same with the residue kept as its shift amount (8 x code): the band kernels carry query residues in that form
+__device__ __forceinline__ int score_at(uint64_t mr, uint32_t q8) { return (int)(int8_t)(mr >> q8); }
 
 // ---------------------------------------------------------------- wave-per-task kernel
 template <int MODE, int C>
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
     for (int c = 0; c < C; ++c) {
         const int d = lane * C + c;
         const int j = d - w;  // column of this diagonal on row 0
-        qc[c] = (j >= 0 && j < qlen) ? q[j] : 0u;
+        qc[c] = (j >= 0 && j < qlen) ? 8u * q[j] : 0u;
         if (MODE == MODE_EXTEND) {
             // first row of eh[] (ksw.c:377-379): h0, max(h0-gapoe,0), then -gape per column while > 0
             int v = 0;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
         const uint64_t mr = prm->matrow[tch];
         // new query character entering the top diagonal on the next row
         const int xq = i + 1 - w + ROWB - 1;
-        const uint32_t qfeed = (xq >= 0 && xq < qlen) ? q[xq] : 0u;
+        const uint32_t qfeed = (xq >= 0 && xq < qlen) ? 8u * q[xq] : 0u;
 
         if (MODE == MODE_EXTEND) {
             if (beg < i - w) beg = i - w;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
         for (int c = 0; c < C; ++c) {
             const int d = lane * C + c;
             act[c] = d >= db && d < de;
-            const int hh = Hd[c] + score_of(mr, qc[c]);
+            const int hh = Hd[c] + score_at(mr, qc[c]);
             const int e = E[c];
             if (MODE == MODE_EXTEND) { A[c] = hh > e ? hh : e; dirH[c] = 0; }
             else { dirH[c] = hh >= e ? 0u : 1u; A[c] = hh >= e ? hh : e; }
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
     for (int c = 0; c < C; ++c) {
         const int d = gl * C + c;
         const int j = d - w;
-        qc[c] = (j >= 0 && j < qlen) ? q[j] : 0u;
+        qc[c] = (j >= 0 && j < qlen) ? 8u * q[j] : 0u;
         if (MODE == MODE_EXTEND) {
             int v = 0;
             if (j == 0) v = h0;
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
         const uint64_t mr_next = s_mat[tnext & 7];
         const uint32_t tnext2 = i + 2 < tlen ? tg[i + 2] : 0u;
         const int xq = i + 1 - w + ROWB - 1;
-        const uint32_t qfeed = (xq >= 0 && xq < qlen) ? q[xq] : 0u;
+        const uint32_t qfeed = (xq >= 0 && xq < qlen) ? 8u * q[xq] : 0u;
 
         if (MODE == MODE_EXTEND) {
             if (beg < i - w) beg = i - w;
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
         for (int c = 0; c < C; ++c) {
             const int d = gl * C + c;
             act[c] = live && d >= db && d < de;
-            const int hh = Hd[c] + score_of(mr, qc[c]);
+            const int hh = Hd[c] + score_at(mr, qc[c]);
             const int e = E[c];
             if (MODE == MODE_EXTEND) { A[c] = hh > e ? hh : e; dirH[c] = 0; }
             else { dirH[c] = hh >= e ? 0u : 1u; A[c] = hh >= e ? hh : e; }
