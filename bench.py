@@ -274,6 +274,22 @@ def main():
             b.launch()
             ffi.sync(dev)
             acc.append(b.kernel_ms)
+    # what overlapping the seed kernel with the DP chains buys: the same timed steps once more with one half left out
+    def half_loop(fn):
+        ffi.sync(dev)
+        torch.cuda.synchronize()
+        time.sleep(0.005)
+        t = time.perf_counter()
+        for st in timed:
+            fn(st)
+        ffi.sync(dev)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / len(timed) * 1e3
+    ffi.set_lazy_join(dev, True)
+    seed_only_ms = half_loop(lambda st: st[0].launch())
+    dp_only_ms = half_loop(lambda st: (st[2].launch(), st[1].launch(), st[3].launch()))
+    ffi.sync(dev)
+    ffi.set_lazy_join(dev, False)
     cells_ext = sum(st[1].cells for st in timed)
     cells_nw = sum(st[2].cells for st in timed)
     cells_gl = sum(st[3].cells for st in timed)
@@ -432,6 +448,9 @@ def main():
             "parallelism": "reads sharded over %d GPU(s), index replicated, no collective" % world,
         },
         "device_ms_total": dev_ms,
+        "step_split": {"seed_only_ms_per_step": seed_only_ms, "dp_only_ms_per_step": dp_only_ms,
+                       "note": "the timed steps issued once more with only the seed launches / only the DP launches (informative): "
+                               "ms_per_step against their sum shows what running them side by side gains"},
         "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
         "dp_gcups": (cells_ext + cells_nw + cells_gl) / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else None,
         "dp_detail": {

@@ -109,6 +109,9 @@ def timeline(path, out, only=""):
         cur_end = e[1] if cur_end is None or not cur[:-1] else max(cur_end, e[1])
     clusters.append(cur)
     big = [c for c in clusters if len(c) >= 100] or clusters
+    # the bench also issues seed-only and DP-only passes: the timed region holds both kinds of kernel
+    both = [c for c in big if any("smam_count" in e[2] for e in c) and any("ksw_" in e[2] for e in c)]
+    big = both or big
     best = max(big, key=lambda c: len(c) / max(1, max(e[1] for e in c) - c[0][0]))
     lo = best[0][0]
     pts = []
