@@ -47,9 +47,10 @@ struct Ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // side streams: independent kernel chains of one batch (one per kernel bin) fork from `stream` and join it again,
     // so that a bin holding a handful of long tasks does not serialise behind (or in front of) the others
-    static constexpr int NSIDE = 8;
+    static constexpr int NSIDE = 14;
     hipStream_t side[NSIDE] = {};
     hipEvent_t side_ev[NSIDE] = {};
+    hipEvent_t l2_ev[6] = {};        // a ksw_lane2 class of a ksw_extend batch is done (its give-up list is complete)
     hipEvent_t fill_ev[3] = {};      // a group bin's fill kernel is done: its two backtrack classes may run side by side
     hipEvent_t fork_ev = nullptr;
     // lazy join (alfa_set_lazy_join): launches leave their side chains unjoined so that successive batches overlap; the

@@ -58,6 +58,7 @@ int Ctx::ensure(int dev) {
         for (auto& st : side) ALFA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         for (auto& e : side_ev) ALFA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : fill_ev) ALFA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : l2_ev) ALFA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ALFA_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
     }
     return ALFA_OK;

@@ -27,9 +27,12 @@
 //     lane-per-task kernel that follows the reference loop literally (the rare tail).
 //   * The kernel bins of a batch run as independent chains on side streams (launch_all).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
+#include <string>
 #include <vector>
 
 #include "device_ctx.h"
@@ -38,6 +41,7 @@ namespace {
 
 constexpr int NEG_INF = -0x40000000;  // MINUS_INF, ksw.c:454
 constexpr int WPB = 4;                // wavefronts (tasks) per workgroup
+constexpr int BAIL_HDR = 64;          // words in front of a give-up list (word 0 = count): the list is zeroed by a 256-byte memset
 enum { MODE_NW = 0, MODE_GLOBAL = 1, MODE_EXTEND = 2 };
 
 struct DevTask {
@@ -400,15 +404,23 @@ template <int MODE, int C, int GL>
 __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __restrict__ tasks, int ntask,
                                                             const uint8_t* __restrict__ seq,
                                                             const DevParams* __restrict__ prm,
-                                                            int32_t* __restrict__ out, uint8_t* __restrict__ zbuf) {
+                                                            int32_t* __restrict__ out, uint8_t* __restrict__ zbuf,
+                                                            const int* __restrict__ ilist) {
+    // ilist != nullptr: run tasks[ilist[BAIL_HDR + k]] for k < ilist[0] (the tasks ksw_lane2_kernel gave up on); ntask bounds the grid
     __shared__ uint64_t s_mat[8];
+    if (ilist) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) ((int*)ilist)[BAIL_HDR + ntask] = ilist[0];      // kept for alfa_dp_batch_giveups
+        ntask = ilist[0] < ntask ? ilist[0] : ntask;
+        if ((int)(blockIdx.x * WPB * (64 / GL)) >= ntask) return;
+    }
     if (threadIdx.x < 8) s_mat[threadIdx.x] = prm->matrow[threadIdx.x];
     __syncthreads();
     const int lane = lane_id();
     const int gl = lane & (GL - 1);
     const int task = (blockIdx.x * WPB + (threadIdx.x >> 6)) * (64 / GL) + lane / GL;
     const bool valid = task < ntask;
-    const DevTask T = tasks[valid ? task : ntask - 1];
+    const int tsel = valid ? task : ntask - 1;
+    const DevTask T = tasks[ilist ? ilist[BAIL_HDR + tsel] : tsel];
     const uint8_t* __restrict__ q = seq + T.qoff;
     const uint8_t* __restrict__ tg = seq + T.toff;
     const int qlen = T.qlen, tlen = valid ? T.tlen : 0, w = T.w;
@@ -930,20 +942,399 @@ __global__ __launch_bounds__(64) void ksw_lane_kernel(const DevTask* __restrict_
     }
 }
 
+// ---------------------------------------------------------------- band-in-registers kernel (ksw_lane2_kernel)
+// The short-read task stream (0.7-1.5 tasks per read, queries of 1-100 residues, bands of 7-49 diagonals,
+// 200-700 cells per task) is inter-task parallel work.  G lanes own a task (G = 1, 2, 4, 8 or 16: 64/G tasks per wavefront),
+// each lane C = ND/G consecutive band diagonals in registers, statically indexed and fully unrolled:
+//   * H(i-1,j-1) -> H(i,j) stays in its register; E moves one register down per row (written in place: slot c-1 is free
+//     once slot c has been read); F is a running register along the row.  No scan, no reduction.
+//   * lanes of a task are SKEWED by one row: in iteration k lane g works on row k - g.  F (and the running row maximum
+//     of ksw_extend) enter lane g from what lane g-1 finished one iteration earlier (one DPP move); the E that lane g's
+//     last slot needs comes from lane g+1's FIRST slot of the same iteration, which is computed C-1 slot steps before it is
+//     read.  The critical path of a task is (rows + G - 1) iterations of C slots instead of rows x ND.
+//   * the query sits in LDS at byte position j + w of the task's string (PAD elsewhere), so slot s of row r reads byte
+//     r + s: one ds_read_b32 per 4 slots, one v_alignbyte + one v_perm_b32 (four scores out of the packed 8-entry matrix
+//     row of the lane's target residue) per 4 slots;
+//   * band limits are one unsigned compare per slot; a slot outside the band keeps its H register (which is how the
+//     first-column values H(i,-1) get in: they are preloaded into the diagonals that reach column 0 later) and feeds
+//     FLOOR into E and F;
+//   * ksw_extend: row maximum and its LAST column (ksw.c:414) are one packed key per slot, (H - gapoe) << 6 | slot;
+//     gscore / max_ie need H(i, qlen-1) of every row: a diagonal that leaves the matrix through the last column is frozen
+//     there, so they are read off the registers once, after the last row.  The kernel only follows the STATIC band: the
+//     band of ksw_extend narrows only where an in-band H is 0 (ksw.c:435-438), so a task that meets one (or a zero
+//     first-column value) gives up and is appended to a list that the row-per-16-lanes kernel then runs.
+//   * ksw_global: four direction BITS per cell (sign bits of the four comparisons, shifted in with v_alignbit) go to LDS,
+//     16 bits per 4 slots, and lane 0 of the task walks them back right after the last row: no direction bytes in HBM, no
+//     second kernel.  Only "regular" tasks come here (|qlen - tlen| <= w, both lengths >= 1): every in-band cell then has
+//     a finite predecessor, so the exact drift of MINUS_INF outside the band (which irregular tasks expose) cannot reach
+//     a result.
+// The row loop must stay ONE basic block (no break, no short-circuit &&): any control flow in it makes the register
+// allocator double-buffer the band.
+constexpr int QPAD = 7;               // query code of positions outside the query: needs m <= 7
+
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }           // v_max3_i32
+// lane i <- lane i-1 / i+1 inside its DPP row of 16 (groups of G lanes never straddle a row); callers mask the group edges
+__device__ __forceinline__ int from_prev_lane(int v) { return dpp<0x111, 0xf>(v, v); }
+__device__ __forceinline__ int from_next_lane(int v) { return dpp<0x101, 0xf>(v, v); }
+
+template <int MODE, int ND, int G>
+__device__ __forceinline__ void lane2_body(const DevTask* __restrict__ tasks, int ntask, const uint8_t* __restrict__ seq,
+                                           const DevParams* __restrict__ prm, int32_t* __restrict__ out,
+                                           uint32_t* __restrict__ cig, int32_t* __restrict__ ncig,
+                                           int* __restrict__ bail, int task_base, int tcap, int blk) {
+    extern __shared__ uint32_t lds2[];
+    constexpr int C = ND / G;         // band diagonals per lane
+    constexpr int TPW = 64 / G;       // tasks per wavefront
+    constexpr int NW4 = C / 4;        // query dwords per lane window
+    constexpr int DH = ND / 4;        // direction half-words per row
+    constexpr int FLOOR = MODE == MODE_EXTEND ? 0 : NEG_INF;
+    static_assert(C % 4 == 0 && C * G == ND && ND <= 64 && (G & (G - 1)) == 0 && G <= 16, "band class");
+    const int lane = threadIdx.x;
+    const int g = lane & (G - 1), tw = lane / G;
+    uint64_t* s_mat = (uint64_t*)lds2;
+    uint32_t* ring = lds2 + 16;
+    const int RW = ((tcap + ND + G + 8) >> 2) + 2;             // dwords of a task's query string
+    const int TW = (tcap + G + 11) >> 2;                       // dwords of a task's target string
+    uint32_t* tring = ring + RW * TPW;
+    uint16_t* dirs = (uint16_t*)(tring + TW * TPW);
+    if (lane < 8) s_mat[lane] = prm->matrow[lane];
+    const int tpos = blk * TPW + tw;
+    const bool valid = tpos < ntask;
+    const DevTask T = tasks[valid ? tpos : ntask - 1];
+    const uint8_t* __restrict__ q = seq + T.qoff;
+    const uint8_t* __restrict__ tg = seq + T.toff;
+    const int qlen = T.qlen, tlen = valid ? T.tlen : 0, w = T.w;
+    const int gapo = prm->gapo, gape = prm->gape, gapoe = gapo + gape;
+    const int zdrop = prm->zdrop;
+    int h0 = T.h0;
+    if (MODE == MODE_EXTEND && h0 < 0) h0 = 0;
+    // ksw_extend: from the first row iz whose first-column value max(h0 - gapo - gape*(i+1), 0) is 0 the reference moves `beg`
+    // up by one per row (ksw.c:435-436 stops at eh[beg].h == 0): the band keeps min(w, iz) diagonals on its left from there on
+    int iz = 0x3fffffff;
+    if (MODE == MODE_EXTEND) {
+        if (h0 <= gapo) iz = 0;
+        else if (gape > 0) iz = (h0 - gapo + gape - 1) / gape - 1;
+        iz = iz < 0 ? 0 : iz;
+    }
+    const int tmax = wave_max(tlen);
+    const int qmax = wave_max(valid ? qlen : 0);
+
+    // ---- the task's query string: PAD everywhere, query residue j at byte j + w (dword d of task tw at ring[d * TPW + tw]);
+    // its target string: residue r at byte r + G (lane g reads byte k + G - g in iteration k), 0 elsewhere
+    for (int d = g; d < RW; d += G) ring[d * TPW + tw] = 0x01010101u * QPAD;
+    for (int d = g; d < TW; d += G) tring[d * TPW + tw] = 0u;
+    __syncthreads();
+    {
+        uint8_t* rb = (uint8_t*)ring;
+        uint8_t* tb = (uint8_t*)tring;
+        const int lim = RW * 4;
+        // four independent byte loads in flight per lane and trip (one load per trip is one memory round trip per byte)
+        for (int j0 = 4 * g; j0 < qmax; j0 += 4 * G) {
+            uint8_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (valid && j0 + u < qlen) ? q[j0 + u] : (uint8_t)QPAD;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = j0 + u + w;
+                if (valid && j0 + u < qlen && p < lim) rb[((p >> 2) * TPW + tw) * 4 + (p & 3)] = v[u];
+            }
+        }
+        for (int j0 = 4 * g; j0 < tmax; j0 += 4 * G) {
+            uint8_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (j0 + u < tlen) ? tg[j0 + u] : (uint8_t)0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = j0 + u + G;
+                if (j0 + u < tlen) tb[((p >> 2) * TPW + tw) * 4 + (p & 3)] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- row -1 / column -1 values of the lane's diagonals (see the header comment)
+    int Hd[C], E[C];
+    const int eh1 = h0 > gapoe ? h0 - gapoe : 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int s = g * C + c;
+        const int j0 = s - w;             // column of diagonal s on row 0
+        int v;
+        if (MODE == MODE_EXTEND) {
+            const int a = eh1 - (j0 - 1) * gape;                          // ksw.c:377-379
+            const int bq = h0 - (gapo + gape * (w - s));                  // H(w-s-1, -1), ksw.c:395-396
+            v = j0 == 0 ? h0 : (j0 > 0 ? a : bq);
+            v = v > 0 ? v : 0;
+            E[c] = 0;
+        } else {
+            const int a = (j0 <= w && j0 <= qlen) ? -(gapo + gape * j0) : NEG_INF;   // ksw.c:486-489 / 558-561
+            const int bq = -(gapo + gape * (w - s));                      // H(w-s-1, -1), ksw.c:497,568
+            v = j0 == 0 ? 0 : (j0 > 0 ? a : bq);
+            E[c] = NEG_INF;
+        }
+        Hd[c] = v;
+    }
+
+    bool done = !valid, give_up = false;
+    int mx = h0, max_i = -1, max_j = -1, max_off = 0, last_row = -1;
+    int quirk_h1 = -1, quirk_i = -1;                   // ksw_extend: the gscore update of the first empty row (j == qlen there)
+    int Flast = FLOOR, klast = 0;
+    uint32_t zlast = 0xffffffffu;
+    uint32_t Wq[NW4 + 1], Wn[NW4 + 1];
+    const int woff = g * (C - 1);                      // byte offset of the lane's window: slot g*C + c of row k - g is byte k + woff + c
+    const int niter = tmax + G - 1;
+    // software pipeline of the LDS reads (their latency would otherwise open every iteration): the query window one
+    // iteration ahead, the target residue two ahead and its matrix row one ahead
+    const uint8_t* tbytes = (const uint8_t*)tring;
+    auto tres = [&](int k) -> uint32_t { const int p = k + G - g; return tbytes[((p >> 2) * TPW + tw) * 4 + (p & 3)]; };
+    {
+        const int d0 = woff >> 2;
+#pragma unroll
+        for (int j = 0; j <= NW4; ++j) Wn[j] = ring[(d0 + j) * TPW + tw];
+    }
+    uint64_t mr_n = s_mat[tres(0) & 7];
+    uint32_t t_n = tres(1);
+
+    for (int k = 0; k < niter; ++k) {
+        const int r = k - g;                           // this lane's row
+        const bool rowv = (r >= 0) & (r < tlen);
+        const uint64_t mr = mr_n;
+        mr_n = s_mat[t_n & 7];
+        t_n = tres(k + 2);
+        const int pos = k + woff;
+#pragma unroll
+        for (int j = 0; j <= NW4; ++j) Wq[j] = Wn[j];
+        {
+            const int d0 = (pos + 1) >> 2;
+#pragma unroll
+            for (int j = 0; j <= NW4; ++j) Wn[j] = ring[(d0 + j) * TPW + tw];
+        }
+        const uint32_t ph = (uint32_t)pos & 3u;
+        const int rdir = rowv ? r : tcap;              // ksw_global: rows outside the task write to a spare row of the direction bits
+        // band of this row in diagonal coordinates: slot s is inside iff db <= s < de
+        const int rz = (MODE == MODE_EXTEND && r > iz) ? iz : r;
+        const int db = w - rz > 0 ? w - rz : 0;
+        int de = qlen - r + w;
+        de = de < 2 * w + 1 ? de : 2 * w + 1;
+        const bool nonempty = de > db;
+        const int sbase = g * C - db;
+        const uint32_t bw = (rowv & nonempty) ? (uint32_t)(de - db) : 0u;
+        int F = FLOOR, kin = 0;
+        uint32_t zin = 0xffffffffu;
+        if (G > 1) {
+            const int fp = from_prev_lane(Flast), kp = from_prev_lane(klast);
+            const uint32_t zp = (uint32_t)from_prev_lane((int)zlast);
+            F = g == 0 ? FLOOR : fp;
+            kin = g == 0 ? 0 : kp;
+            zin = g == 0 ? 0xffffffffu : zp;
+        }
+        int kown = 0;
+        uint32_t zmin = zin;
+        uint32_t acc = 0;
+        int e_last = FLOOR;                            // E of the lane's last slot: lane g+1's first slot of this iteration
+#pragma unroll
+        for (int k4 = 0; k4 < NW4; ++k4) {
+            const uint32_t sel = __builtin_amdgcn_alignbyte(Wq[k4 + 1], Wq[k4], ph);
+            const uint32_t sc4 = __builtin_amdgcn_perm((uint32_t)(mr >> 32), (uint32_t)mr, sel);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int c = k4 * 4 + b;
+                const bool act = (uint32_t)(c + sbase) < bw;
+                const int hh = Hd[c] + (int)(int8_t)(sc4 >> (8 * b));
+                const int e = (c == C - 1) ? e_last : E[c];
+                int t, en;
+                if (MODE == MODE_EXTEND) {
+                    const int h = max3i(hh, e, F);
+                    Hd[c] = act ? h : Hd[c];
+                    t = act ? sub_floor0(h, gapoe) : 0;
+                    zmin = min(zmin, act ? (uint32_t)h : 0xffffffffu);
+                    en = max(sub_floor0(e, gape), t);
+                    F = max(sub_floor0(F, gape), t);
+                    kown = max(kown, (t << 6) | c);
+                } else if (MODE == MODE_NW) {
+                    const int h = max3i(hh, e, F);
+                    Hd[c] = act ? h : Hd[c];
+                    t = act ? h - gapoe : NEG_INF;
+                    en = max(e - gape, t);
+                    F = max(F - gape, t);
+                } else {
+                    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)(hh - e), 31);          // hh < e: came from E (ksw.c:506)
+                    const int A = max(hh, e);
+                    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)(A - F), 31);           // < F: came from F
+                    const int h = max(A, F);
+                    Hd[c] = act ? h : Hd[c];
+                    t = act ? h - gapoe : NEG_INF;
+                    const int e2 = e - gape;
+                    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)(t - e2), 31);          // e2 > t: E extends
+                    en = max(e2, t);
+                    const int f2 = F - gape;
+                    acc = __builtin_amdgcn_alignbit(acc, (uint32_t)(t - f2), 31);          // f2 > t: F extends
+                    F = max(f2, t);
+                    if (b == 3) dirs[(rdir * DH + (g * C + c) / 4) * TPW + tw] = (uint16_t)acc;
+                }
+                if (c > 0) E[c - 1] = en;
+                else if (G > 1) { const int nx = from_next_lane(en); e_last = g == G - 1 ? FLOOR : nx; }
+            }
+            // keep the slots in program order: left to itself the scheduler runs the F chain of the whole row first and
+            // keeps every H of the row live (twice the registers, half the waves per SIMD)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        Flast = F;
+
+        if (MODE == MODE_EXTEND) {
+            // the row's packed maximum: slots of this lane, then the lanes before it (ties -> the later column)
+            const int tkey = max(kin, kown + g * C);
+            klast = tkey;
+            zlast = zmin;
+            // row epilogue of ksw_extend (ksw.c:424-433), branch-free; only the task's last lane has the whole row
+            const bool live = rowv & !done;
+            const int beg = r - w + db;                      // = max(r - w, 0) before row iz
+            int end = r + w + 1;
+            end = end < qlen ? end : qlen;
+            int h1i = h0 - (gapo + gape * (r + 1));
+            h1i = h1i > 0 ? h1i : 0;
+            const bool row_empty = live & !nonempty;       // the reference's j loop does not run: m == 0 -> break
+            const bool quirk = row_empty & (beg == qlen);  // ... after the gscore update fired with h1_init (j == qlen)
+            const bool row_on = live & nonempty;
+            const bool narrow = row_on & ((zmin == 0u) | ((tkey >> 6) == 0));   // the band may narrow (ksw.c:435-438)
+            const bool row_ok = row_on & !narrow;
+            const int m = (tkey >> 6) + gapoe;
+            const int mj = r - w + (tkey & 63);
+            int dlt = (r - max_i) - (end - max_j);
+            dlt = dlt < 0 ? -dlt : dlt;
+            const bool zd = row_ok & (zdrop > 0) & (mx - m - dlt * gape > zdrop);         // ksw.c:429 (no short circuit: no branch)
+            const bool upd = row_ok & !zd & (m > mx);
+            int off = mj - r;
+            off = off < 0 ? -off : off;
+            last_row = live ? r : last_row;
+            quirk_h1 = quirk ? h1i : quirk_h1;
+            quirk_i = quirk ? r : quirk_i;
+            give_up = give_up | narrow;
+            done = done | row_empty | narrow | zd;
+            max_off = (upd & (off > max_off)) ? off : max_off;
+            max_i = upd ? r : max_i;
+            max_j = upd ? mj : max_j;
+            mx = upd ? m : mx;
+        }
+    }
+
+    // ---- results: the state of ksw_extend lives in the task's last lane, H values in whichever lane owns the diagonal
+    const int lane_last = lane | (G - 1), lane_first = lane & ~(G - 1);
+    if (MODE == MODE_EXTEND) {
+        const int lr = __shfl(last_row, lane_last, 64);
+        // gscore / max_ie: H(i, qlen-1) of row i = qlen-1+w-s is what diagonal s froze at (ties -> the later row, ksw.c:426)
+        int gk = -1;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int s = g * C + c;
+            const int is = qlen - 1 + w - s;
+            const bool ok = (s <= 2 * w) & (is >= 0) & (is <= lr);
+            const int key = (Hd[c] << 6) | (63 - s);
+            gk = (ok & (key > gk)) ? key : gk;
+        }
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) gk = max(gk, __shfl_xor(gk, o, 64));
+        if (!valid || g != G - 1) return;
+        if (give_up) {
+            const int slot = atomicAdd(bail, 1);
+            bail[BAIL_HDR + slot] = task_base + tpos;
+            return;
+        }
+        int gscore = -1, max_ie = -1;
+        if (gk >= 0) { gscore = gk >> 6; max_ie = qlen - 1 + w - (63 - (gk & 63)); }
+        if (quirk_i >= 0 && !(gscore > quirk_h1)) { gscore = quirk_h1; max_ie = quirk_i; }
+        ExtOut* o = (ExtOut*)out + T.orig;
+        o->score = mx; o->qle = max_j + 1; o->tle = max_i + 1; o->gtle = max_ie + 1; o->gscore = gscore; o->max_off = max_off;
+        return;
+    }
+    // NW / GLOBAL: eh[qlen].h = H(tlen-1, qlen-1), frozen in diagonal qlen - tlen + w
+    {
+        const int dl = qlen - tlen + w;
+        int score = (int)0x80000000;
+#pragma unroll
+        for (int c = 0; c < C; ++c) score = (g * C + c == dl) ? Hd[c] : score;
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) score = max(score, __shfl_xor(score, o, 64));
+        if (valid && g == 0) out[T.orig] = score;
+    }
+    if (MODE == MODE_GLOBAL) {
+        __syncthreads();
+        if (!valid || lane != lane_first) return;
+        uint32_t* slot = cig + T.cigoff;
+        int pos = T.cigcap, n = 0;
+        uint32_t cur_op = 0xffffffffu, cur_len = 0;
+        auto push = [&](uint32_t op, uint32_t len) {
+            if (op == cur_op) { cur_len += len; return; }
+            if (cur_op != 0xffffffffu) { slot[--pos] = cur_len << 4 | cur_op; ++n; }
+            cur_op = op; cur_len = len;
+        };
+        int i = tlen - 1, kq = qlen - 1, which = 0;         // regular task: min(i+w+1, qlen) == qlen
+        while (i >= 0 && kq >= 0) {
+            const int s = kq - i + w;
+            const uint32_t wd = dirs[(i * DH + (s >> 2)) * TPW + tw];
+            const uint32_t nib = (wd >> (12 - 4 * (s & 3))) & 15u;
+            if (which == 0) which = (nib & 4u) ? 2 : (int)((nib >> 3) & 1u);
+            else if (which == 1) which = (nib & 2u) ? 1 : 0;
+            else which = (nib & 1u) ? 2 : 0;
+            if (which == 0) { push(0, 1); --i; --kq; }
+            else if (which == 1) { push(2, 1); --i; }
+            else { push(1, 1); --kq; }
+        }
+        if (i >= 0) push(2, (uint32_t)(i + 1));
+        if (kq >= 0) push(1, (uint32_t)(kq + 1));
+        if (cur_op != 0xffffffffu) { slot[--pos] = cur_len << 4 | cur_op; ++n; }
+        ncig[T.orig] = n;
+    }
+}
+
+// One launch per ksw kind: the grid is the concatenation of the classes' blocks (the box gives a process 4 hardware queues:
+// a launch per class and chunk would serialise on them), long-target classes first.
+constexpr int NL2 = 6;
+struct L2Grid { int blk_end[NL2]; int task_start[NL2]; int task_cnt[NL2]; int tcap[NL2]; };
+template <int MODE>
+__global__ __launch_bounds__(64) void ksw_lane2_kernel(L2Grid L, const DevTask* __restrict__ tasks, const uint8_t* __restrict__ seq,
+                                                      const DevParams* __restrict__ prm, int32_t* __restrict__ out,
+                                                      uint32_t* __restrict__ cig, int32_t* __restrict__ ncig, int* __restrict__ bail) {
+    const int b = blockIdx.x;
+    int k = 0;
+    while (k < NL2 - 1 && b >= L.blk_end[k]) ++k;
+    const int blk = b - (k ? L.blk_end[k - 1] : 0);
+    const DevTask* t = tasks + L.task_start[k];
+    const int n = L.task_cnt[k], base = L.task_start[k], tcap = L.tcap[k];
+    // the classes with the long targets are the launch's critical path: their wavefronts issue ahead of the others on a SIMD
+    if (k == 0) __builtin_amdgcn_s_setprio(3);
+    else if (k <= 2) __builtin_amdgcn_s_setprio(2);
+    switch (k) {
+    case 0: lane2_body<MODE, 64, 16>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
+    case 1: lane2_body<MODE, 32, 8>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
+    case 2: lane2_body<MODE, 16, 4>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
+    case 3: lane2_body<MODE, 48, 4>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
+    case 4: lane2_body<MODE, 32, 2>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
+    default: lane2_body<MODE, 16, 1>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
+    }
+}
+
 }  // namespace
 
 // ================================================================= host side
+constexpr int NBIN = 16;
+constexpr int L2BIN = 9;        // first lane2 bin (NL2 classes, then ksw_global's long targets: class 0 in a launch of its own)
+constexpr int L2_TCAP = 512;    // longest target (rows) of the band-in-registers kernel
 struct alfa_dp_batch {
     int mode = 0, n = 0, device = 0;
     DevParams hp;
     std::vector<DevTask> ht;        // device order, .orig already remapped to the dense output index
     std::vector<int> dense_of;      // device order -> caller index
-    int bin_cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // lane kernel (qlen <= 30, 62, 126), group kernel C=1,2,4, wave kernel C=2,4, generic
+    // lane kernel (qlen <= 30, 62, 126), group kernel C=1,2,4, wave kernel C=2,4, generic, lane2 kernel classes (L2_CLASS)
+    int bin_cnt[NBIN] = {};
+    L2Grid l2grid, l2big;           // ksw_lane2_kernel: blocks, tasks and longest target of each class; l2big = ksw_global's long targets
+    int l2blocks = 0, l2big_blocks = 0;
+    size_t l2lds = 0, l2big_lds = 0;
     int nbig[3] = {0, 0, 0};        // group bins: tasks whose direction matrix exceeds ZC bytes (a prefix: sorted by tlen)
     int nlong[3] = {0, 0, 0};       // ... of which targets of at least LONG_TLEN rows (a shorter prefix): tiled wave-per-task backtrack
     int64_t cig_words = 0, cells = 0, zbytes = 0, eh_items = 0;
     size_t seq_bytes = 0, out_bytes = 0;
-    alfa::DevBuf d_seq, d_tasks, d_out, d_z, d_cig, d_eh;
+    alfa::DevBuf d_seq, d_tasks, d_out, d_z, d_cig, d_eh, d_bail;
     alfa::PinBuf h_out, h_cig;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool launched = false;
@@ -991,6 +1382,39 @@ int64_t band_cells(int64_t qlen, int64_t tlen, int64_t w) {
     return c;
 }
 
+// ksw_lane2_kernel's classes, in grid order (long targets first): ND band diagonals over G lanes.  A band width has a
+// narrow form for short targets (few lanes per task: least work per cell) and a wide form for long ones (the task's
+// critical path is (rows + G - 1) x ND/G slots).  max_rows[0] bounds ksw_nw / ksw_extend, max_rows[1] ksw_global, whose
+// direction bits (ND/2 bytes per row and task, 64/G tasks per wavefront) must fit the LDS budget of a workgroup.
+struct L2Class { int nd, g, max_rows[2]; };
+constexpr L2Class L2_CLASS[NL2] = {{64, 16, {512, 160}}, {32, 8, {512, 128}}, {16, 4, {512, 128}},
+                                   {48, 4, {64, 40}},    {32, 2, {40, 24}},   {16, 1, {48, 32}}};
+size_t lane2_lds(int mode, int nd, int g, int tcap) {
+    const size_t tpw = 64 / g;
+    const size_t rw = (size_t)((tcap + nd + g + 8) >> 2) + 2;
+    const size_t tw = (size_t)(tcap + g + 11) >> 2;
+    return 64 + (rw + tw) * tpw * 4 + (mode == MODE_GLOBAL ? (size_t)(tcap + 1) * (nd / 4) * tpw * 2 : 0);
+}
+int lane2_class(int mode, const alfa_dp_params* p, const alfa_dp_task& x, int w) {
+    static const bool off = getenv("ALFA_DP_NO_LANE2") != nullptr;
+    if (off || p->m > QPAD || x.qlen < 1 || x.tlen < 1) return -1;
+    const int W = 2 * w + 1;
+    if (W > 64) return -1;
+    if (mode == MODE_EXTEND) {
+        // scores stay far below 2^25 (packed row-maximum key)
+        int maxs = 0;
+        for (int i = 0; i < p->m * p->m; ++i) maxs = std::max<int>(maxs, p->mat[i]);
+        const int h0 = x.h0 < 0 ? 0 : x.h0;
+        if ((int64_t)h0 + (int64_t)x.qlen * maxs >= (1 << 24)) return -1;
+    } else if (std::abs(x.qlen - x.tlen) > w) return -1;         // "regular" tasks only (see the kernel's header comment)
+    // the narrowest class that holds the band and the target: classes 5, 4, 3 (narrow forms) before 2, 1, 0
+    static const int pref[NL2] = {5, 2, 4, 1, 3, 0};
+    for (int k : pref)
+        if (W <= L2_CLASS[k].nd && x.tlen <= L2_CLASS[k].max_rows[mode == MODE_GLOBAL]) return k;
+    if (mode == MODE_GLOBAL && x.tlen <= L2_TCAP) return NL2;   // class 0 with more LDS than the common launch is given
+    return -1;
+}
+
 template <int MODE, int C>
 void launch_wave(hipStream_t st, const DevTask* d_tasks, int n, const uint8_t* d_seq, const DevParams* d_prm, int32_t* d_out, uint8_t* d_z) {
     if (n <= 0) return;
@@ -1009,11 +1433,11 @@ void launch_group(hipStream_t st, const DevTask* d_tasks, int n, const uint8_t* 
     if (!half_rows) {
         const int per_block = WPB * 4;
         hipLaunchKernelGGL((ksw_group_kernel<MODE, C, 16>), dim3((n + per_block - 1) / per_block), dim3(64 * WPB), 0, st, d_tasks, n, d_seq, d_prm,
-                           d_out, d_z);
+                           d_out, d_z, (const int*)nullptr);
     } else {
         const int per_block = WPB * 8;
         hipLaunchKernelGGL((ksw_group_kernel<MODE, 2 * C, 8>), dim3((n + per_block - 1) / per_block), dim3(64 * WPB), 0, st, d_tasks, n, d_seq, d_prm,
-                           d_out, d_z);
+                           d_out, d_z, (const int*)nullptr);
     }
 }
 
@@ -1098,13 +1522,43 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
             hipLaunchKernelGGL(ksw_backtrack_tile_kernel, dim3(bc[7]), dim3(64), 0, s2, d_t + o, bc[7], d_z, d_cig, d_ncig, 64 * 4);
     }
     o += bc[7];
+    const int o8 = o;
+    o += bc[8];
+    // short tasks: a lane per task (ksw_lane2_kernel); ksw_extend tasks whose band starts to narrow come back in a list
+    // (count in word 0, task positions from word BAIL_HDR on) and run in the 16-lanes-per-task kernel on the same stream
+    {
+        int* d_bail = b->d_bail.as<int>();
+        int n_l2 = 0;
+        for (int g = 0; g < NL2; ++g) n_l2 += bc[L2BIN + g];
+        if (n_l2 + bc[L2BIN + NL2] > 0) {
+            // the give-up list's count is zero here (zeroed at create and again after every pass over the list)
+            hipStream_t s8 = side(8);
+            if (n_l2)
+                hipLaunchKernelGGL((ksw_lane2_kernel<MODE>), dim3(b->l2blocks), dim3(64), b->l2lds, s8, b->l2grid, d_t, d_seq, d_prm, d_out, d_cig,
+                                   d_ncig, d_bail);
+            if (b->l2big_blocks && b->l2big_lds > 48 * 1024) {
+                static std::atomic<bool> raised[64];
+                if (!raised[b->device & 63].exchange(true))
+                    (void)hipFuncSetAttribute((const void*)ksw_lane2_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            }
+            if (b->l2big_blocks)
+                hipLaunchKernelGGL((ksw_lane2_kernel<MODE>), dim3(b->l2big_blocks), dim3(64), b->l2big_lds, side(9), b->l2big, d_t, d_seq, d_prm, d_out,
+                                   d_cig, d_ncig, d_bail);
+            if (MODE == MODE_EXTEND && n_l2) {
+                const int per_block = WPB * 4;
+                hipLaunchKernelGGL((ksw_group_kernel<MODE_EXTEND, 4, 16>), dim3((n_l2 + per_block - 1) / per_block), dim3(64 * WPB), 0, s8, d_t,
+                                   n_l2, d_seq, d_prm, d_out, d_z, (const int*)d_bail);
+                (void)hipMemsetAsync(d_bail, 0, sizeof(int) * BAIL_HDR, s8);
+            }
+        }
+    }
     bool any = false;
     for (int k = 0; k < alfa::Ctx::NSIDE; ++k)
         if (used[k]) { (void)hipEventRecord(cx->side_ev[k], cx->side[k]); any = true; }
     if (any) cx->sides_pending = true;
     if (!cx->lazy_join) (void)cx->join_sides();
     if (bc[8])
-        hipLaunchKernelGGL((ksw_lane_kernel<MODE, false>), dim3((bc[8] + 63) / 64), dim3(64), 0, st, d_t + o, bc[8], d_seq, d_prm, d_out,
+        hipLaunchKernelGGL((ksw_lane_kernel<MODE, false>), dim3((bc[8] + 63) / 64), dim3(64), 0, st, d_t + o8, bc[8], d_seq, d_prm, d_out,
                            b->d_eh.as<int2>(), d_z, d_cig, d_ncig, 0);
 }
 
@@ -1114,7 +1568,8 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
     if (rc) return rc;
     b->mode = mode; b->n = n; b->device = cx->device; b->launched = false; b->kernel_ms = 0;
     b->cig_words = b->cells = b->zbytes = b->eh_items = 0;
-    for (int k = 0; k < 9; ++k) b->bin_cnt[k] = 0;
+    for (int k = 0; k < NBIN; ++k) b->bin_cnt[k] = 0;
+    b->l2blocks = b->l2big_blocks = 0; b->l2lds = b->l2big_lds = 0;
     for (int k = 0; k < 3; ++k) b->nbig[k] = b->nlong[k] = 0;
     b->ht.resize((size_t)n);
     b->dense_of.resize((size_t)n);
@@ -1134,7 +1589,12 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         if (x.qlen == 0 || x.tlen == 0) bin = 8;
         else if (lane_work > 0 && x.qlen <= 126 && (int64_t)x.tlen * std::min<int64_t>(x.qlen, 2 * (int64_t)w_eff[i] + 1) <= lane_work)
             bin = x.qlen <= 30 ? 0 : x.qlen <= 62 ? 1 : 2;
-        else { const int W = 2 * w_eff[i] + 1; bin = W <= 16 ? 3 : W <= 32 ? 4 : W <= 64 ? 5 : W <= 128 ? 6 : W <= 256 ? 7 : 8; }
+        else {
+            const int W = 2 * w_eff[i] + 1;
+            bin = W <= 16 ? 3 : W <= 32 ? 4 : W <= 64 ? 5 : W <= 128 ? 6 : W <= 256 ? 7 : 8;
+            const int l2 = lane2_class(mode, p, x, w_eff[i]);
+            if (l2 >= 0) bin = L2BIN + l2;
+        }
         bins[i] = bin;
         b->bin_cnt[bin]++;
         if (bin >= 3 && bin <= 5 && (int64_t)x.tlen * (GL16 << (bin - 3)) > ZC) b->nbig[bin - 3]++;
@@ -1163,10 +1623,10 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
     DevTask* ht = (DevTask*)(hprm + 1);
     *hprm = b->hp;
     size_t so = 0;
-    const int rowb[9] = {0, 0, 0, GL16 * 1, GL16 * 2, GL16 * 4, 64 * 2, 64 * 4, 0};     // direction bytes per row
+    const int rowb[NBIN] = {0, 0, 0, GL16 * 1, GL16 * 2, GL16 * 4, 64 * 2, 64 * 4, 0};     // direction bytes per row (HBM); 0 for the lane2 bins
     const int m = b->hp.m;
-    int bin_start[10] = {0};
-    for (int k = 0; k < 9; ++k) bin_start[k + 1] = bin_start[k] + b->bin_cnt[k];
+    int bin_start[NBIN + 1] = {0};
+    for (int k = 0; k < NBIN; ++k) bin_start[k + 1] = bin_start[k] + b->bin_cnt[k];
     int64_t wave_zbase = 0;
     int wave_nc = 0;
     for (int k = 0; k < n; ++k) {
@@ -1205,7 +1665,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
             } else {
                 d.zoff = b->zbytes;
                 if (bins[li] == 8) b->zbytes += std::min<int64_t>(x.qlen, 2 * (int64_t)d.w + 1) * x.tlen;
-                else b->zbytes += (int64_t)x.tlen * rowb[bins[li]];
+                else b->zbytes += (int64_t)x.tlen * rowb[bins[li]];      // lane2 bins keep their direction bits in LDS
                 b->zbytes = (b->zbytes + 15) & ~(int64_t)15;
             }
             d.cigoff = b->cig_words;
@@ -1214,6 +1674,29 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         }
         b->cells += band_cells(x.qlen, x.tlen, d.w);
         b->ht[k] = d;
+    }
+    // ksw_lane2_kernel's grid: the classes' blocks one after the other; LDS for the neediest class
+    int n_l2 = 0;
+    for (int g = 0; g < NL2; ++g) {
+        const int s0 = bin_start[L2BIN + g], cnt = b->bin_cnt[L2BIN + g];
+        const int tpw = 64 / L2_CLASS[g].g;
+        n_l2 += cnt;
+        b->l2blocks += (cnt + tpw - 1) / tpw;
+        b->l2grid.blk_end[g] = b->l2blocks;
+        b->l2grid.task_start[g] = s0;
+        b->l2grid.task_cnt[g] = cnt;
+        b->l2grid.tcap[g] = cnt ? b->ht[s0].tlen : 1;             // tasks of a bin are ordered longest target first
+        if (cnt) b->l2lds = std::max(b->l2lds, lane2_lds(mode, L2_CLASS[g].nd, L2_CLASS[g].g, b->l2grid.tcap[g]));
+    }
+    if (b->bin_cnt[L2BIN + NL2]) {
+        const int s0 = bin_start[L2BIN + NL2], cnt = b->bin_cnt[L2BIN + NL2], tpw = 64 / L2_CLASS[0].g;
+        b->l2big_blocks = (cnt + tpw - 1) / tpw;
+        for (int g = 0; g < NL2; ++g) { b->l2big.blk_end[g] = b->l2big_blocks; b->l2big.task_start[g] = s0; b->l2big.task_cnt[g] = g ? 0 : cnt; b->l2big.tcap[g] = b->ht[s0].tlen; }
+        b->l2big_lds = lane2_lds(mode, L2_CLASS[0].nd, L2_CLASS[0].g, b->ht[s0].tlen);
+    }
+    if (mode == MODE_EXTEND && n_l2) {
+        if ((rc = b->d_bail.reserve(sizeof(int) * ((size_t)n_l2 + BAIL_HDR + 1)))) return rc;
+        ALFA_HIP(hipMemsetAsync(b->d_bail.p, 0, sizeof(int) * BAIL_HDR, cx->stream));       // synchronised with the copies below
     }
     b->out_bytes = (mode == MODE_EXTEND ? sizeof(ExtOut) : sizeof(int32_t)) * (size_t)n;
     if ((rc = b->d_out.reserve(b->out_bytes)) || (rc = b->h_out.reserve(b->out_bytes))) return rc;
@@ -1295,7 +1778,7 @@ int current_ctx(Ctx** out, int device = -1) {
 }
 
 void release_batch(alfa_dp_batch* b) {
-    b->d_seq.release(); b->d_tasks.release(); b->d_out.release(); b->d_z.release(); b->d_cig.release(); b->d_eh.release();
+    b->d_seq.release(); b->d_tasks.release(); b->d_out.release(); b->d_z.release(); b->d_cig.release(); b->d_eh.release(); b->d_bail.release();
     b->h_out.release(); b->h_cig.release();
     if (b->ev0) { (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); b->ev0 = b->ev1 = nullptr; }
 }
@@ -1401,6 +1884,17 @@ int alfa_dp_batch_fetch(alfa_dp_batch* b, void* out, uint32_t** cigar, int32_t* 
     return ALFA_OK;
 }
 int64_t alfa_dp_batch_cells(const alfa_dp_batch* b) { return b ? b->cells : 0; }
+int64_t alfa_dp_batch_giveups(alfa_dp_batch* b, int64_t* n_fast) {
+    if (!b) return -1;
+    int64_t n_l2 = 0;
+    for (int g = 0; g < NL2; ++g) n_l2 += b->bin_cnt[L2BIN + g];
+    if (n_fast) *n_fast = n_l2;
+    if (b->mode != MODE_EXTEND || n_l2 == 0 || !b->launched) return 0;
+    if (alfa_sync(b->device) != ALFA_OK) return -1;
+    int cnt = 0;
+    if (hipMemcpy(&cnt, b->d_bail.as<int>() + BAIL_HDR + n_l2, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return cnt;
+}
 double alfa_dp_batch_kernel_ms(const alfa_dp_batch* b) {
     if (!b || !b->launched || b->n == 0) return 0;
     float ms = 0;
@@ -1451,3 +1945,93 @@ int alfa_timer_stop(int device, double* ms) {
 }
 
 }  // extern "C"
+
+// ================================================================= ksw_global without any allocation
+// alfa_ksw_global_noalloc (include/alfa_hot.h): the device-resident form of alfa_ksw_global_batch for callers that cannot
+// call hipMalloc (HIP graph capture, tight serving loops).  Inputs and outputs are the caller's device buffers; what the
+// library otherwise allocates per batch -- the scoring parameters, the internal task records and the direction bytes of
+// the fill kernel -- lives in one file-scope device array.  Each GPU holds its own copy of that array at its own address:
+// the address is looked up once per device with hipGetSymbolAddress and only that pointer is ever handed to kernels.
+// The kernels are the ones of the allocating entry point (ksw_wave_kernel<GLOBAL,4> + ksw_backtrack_tile_kernel).
+namespace {
+
+constexpr size_t NOALLOC_HDR = 256;                               // DevParams at the front of the array
+constexpr int NOALLOC_ROWB = 64 * 4;                              // direction bytes per row of ksw_wave_kernel<GLOBAL,4>
+static __device__ __align__(256) unsigned char scratch[ALFA_NOALLOC_SCRATCH_BYTES];
+
+std::mutex g_scratch_mu;
+unsigned char* g_scratch_ptr[64] = {};                            // per device: device address of that GPU's `scratch`
+
+// device address of `scratch` on `device` (which must be current); looked up once per device
+int scratch_for(int device, unsigned char** out) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        ALFA_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return alfa::fail(ALFA_EHIP, "hipGetSymbolAddress returned a null address for the scratch array");
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return ALFA_OK;
+}
+
+// caller's task records -> the kernels' DevTask records (in the scratch array); a task outside the entry point's envelope
+// becomes a harmless 1 x 1 task on the first bytes of d_seq and is flagged (DevTask::pad) for noalloc_finish_kernel
+__global__ void noalloc_prep_kernel(DevParams hp, const alfa_dev_task* __restrict__ t, int n, int max_tlen, int cig_stride,
+                                    unsigned char* __restrict__ ws, int64_t zbase) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *(DevParams*)ws = hp;
+    if (i >= n) return;
+    const alfa_dev_task x = t[i];
+    DevTask d;
+    d.qoff = x.qoff; d.toff = x.toff;
+    d.zoff = zbase + (int64_t)i * max_tlen * NOALLOC_ROWB;
+    d.cigoff = (int64_t)i * cig_stride;
+    d.ehoff = 0;
+    d.qlen = x.qlen; d.tlen = x.tlen; d.h0 = 0;
+    const int lim = x.qlen > x.tlen ? x.qlen : x.tlen;
+    d.w = x.w < lim ? x.w : lim;                                  // the band never binds beyond max(qlen, tlen): identical loops
+    d.orig = i; d.cigcap = cig_stride; d.cigcap2 = 0; d.pad = 0;
+    const bool ok = x.qlen >= 1 && x.tlen >= 1 && x.tlen <= max_tlen && x.w >= 0 && 2 * (int64_t)d.w + 1 <= NOALLOC_ROWB &&
+                    x.qoff >= 0 && x.toff >= 0 && (int64_t)x.qlen + x.tlen + 2 <= cig_stride;
+    if (!ok) { d.qoff = d.toff = 0; d.qlen = d.tlen = 1; d.w = 0; d.pad = 1; }
+    ((DevTask*)(ws + NOALLOC_HDR))[i] = d;
+}
+__global__ void noalloc_finish_kernel(const unsigned char* __restrict__ ws, int n, int32_t* __restrict__ score, int32_t* __restrict__ ncig) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (((const DevTask*)(ws + NOALLOC_HDR))[i].pad) { score[i] = (int32_t)0x80000000; ncig[i] = -2; }
+}
+
+}  // namespace
+
+extern "C" int alfa_ksw_global_noalloc(const alfa_dp_params* p, const alfa_dev_task* d_tasks, int n, int max_tlen, const uint8_t* d_seq,
+                                       int32_t* d_score, uint32_t* d_cigar, int32_t* d_n_cigar, int cig_stride, int device, void* stream) {
+    DevParams hp;
+    int rc = pack_params(p, &hp);
+    if (rc) return rc;
+    if (n < 0 || max_tlen < 1 || cig_stride < 3) return alfa::fail(ALFA_EINVAL, "alfa_ksw_global_noalloc: n < 0, max_tlen < 1 or cig_stride < 3");
+    if (n == 0) return ALFA_OK;
+    if (!d_tasks || !d_seq || !d_score || !d_cigar || !d_n_cigar) return alfa::fail(ALFA_EINVAL, "alfa_ksw_global_noalloc: null device pointer");
+    if (device < 0 || device >= 64 || device >= alfa::device_count())
+        return alfa::fail(alfa::device_count() <= 0 ? ALFA_ENODEV : ALFA_EINVAL, "alfa_ksw_global_noalloc: no such HIP device");
+    const size_t tasks_bytes = ((size_t)n * sizeof(DevTask) + 255) & ~(size_t)255;
+    const size_t need = NOALLOC_HDR + tasks_bytes + (size_t)n * (size_t)max_tlen * NOALLOC_ROWB;
+    if (need > (size_t)ALFA_NOALLOC_SCRATCH_BYTES)
+        return alfa::fail(ALFA_EINVAL, "alfa_ksw_global_noalloc: n * (64 + 256 * max_tlen) = " + std::to_string(need) +
+                                           " bytes exceeds the fixed scratch array of " + std::to_string((size_t)ALFA_NOALLOC_SCRATCH_BYTES) +
+                                           " bytes; split the batch");
+    ALFA_HIP(hipSetDevice(device));
+    unsigned char* ws = nullptr;
+    if ((rc = scratch_for(device, &ws))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t zbase = (int64_t)(NOALLOC_HDR + tasks_bytes);
+    const DevParams* d_prm = (const DevParams*)ws;
+    const DevTask* d_t = (const DevTask*)(ws + NOALLOC_HDR);
+    hipLaunchKernelGGL(noalloc_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, hp, d_tasks, n, max_tlen, cig_stride, ws, zbase);
+    hipLaunchKernelGGL((ksw_wave_kernel<MODE_GLOBAL, 4>), dim3((n + WPB - 1) / WPB), dim3(64 * WPB), 0, st, d_t, n, d_seq, d_prm, d_score, ws);
+    hipLaunchKernelGGL(ksw_backtrack_tile_kernel, dim3(n), dim3(64), 0, st, d_t, n, ws, d_cigar, d_n_cigar, NOALLOC_ROWB);
+    hipLaunchKernelGGL(noalloc_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, n, d_score, d_n_cigar);
+    ALFA_HIP(hipGetLastError());
+    return ALFA_OK;
+}

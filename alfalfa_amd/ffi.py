@@ -446,6 +446,14 @@ class DpBatch:
     def kernel_ms(self):
         return lib().alfa_dp_batch_kernel_ms(self._h)
 
+    def giveups(self):
+        """(tasks in the band-in-registers kernel, ksw_extend tasks that left it in the last launch)"""
+        L = lib()
+        L.alfa_dp_batch_giveups.restype = C.c_int64
+        nf = C.c_int64(0)
+        g = L.alfa_dp_batch_giveups(self._h, C.byref(nf))
+        return int(nf.value), int(g)
+
     def __del__(self):
         try:
             if self._h:
@@ -510,3 +518,18 @@ def timer_stop(device=0):
     ms = C.c_double()
     check(lib().alfa_timer_stop(int(device), C.byref(ms)))
     return ms.value
+
+
+# ---- ksw_global for callers that cannot allocate (alfa_ksw_global_noalloc): every array is a device pointer
+DEV_TASK_DTYPE = np.dtype([("qoff", "<i8"), ("toff", "<i8"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("pad", "<i4")])
+NOALLOC_SCRATCH_BYTES = 32 << 20
+
+
+def ksw_global_noalloc(params, d_tasks_ptr, n, max_tlen, d_seq_ptr, d_score_ptr, d_cigar_ptr, d_ncig_ptr, cig_stride, device=0, stream=0):
+    """Thin binding: all *_ptr are integer device addresses (e.g. torch tensor .data_ptr()); enqueues only."""
+    L = lib()
+    L.alfa_ksw_global_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_int, C.c_void_p]
+    rc = L.alfa_ksw_global_noalloc(C.byref(params), d_tasks_ptr, int(n), int(max_tlen), d_seq_ptr, d_score_ptr, d_cigar_ptr, d_ncig_ptr,
+                                   int(cig_stride), int(device), stream)
+    check(rc)

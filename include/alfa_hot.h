@@ -190,6 +190,9 @@ int     alfa_dp_batch_launch(alfa_dp_batch*);
 /* out: alfa_extend_result[n] (EXTEND) or int32 score[n]; cigar/n_cigar/cig_off as alfa_ksw_global_batch (GLOBAL only, else NULL) */
 int     alfa_dp_batch_fetch(alfa_dp_batch*, void* out, uint32_t** cigar, int32_t* n_cigar, int64_t* cig_off);
 int64_t alfa_dp_batch_cells(const alfa_dp_batch*);       /* inner-loop cells of the static band envelope */
+/* diagnostics: *n_fast = tasks of the batch that run in the band-in-registers kernel; returns how many ksw_extend tasks of the
+ * last launch left it for the row-per-16-lanes kernel because their band started to narrow (synchronises; -1 on error) */
+int64_t alfa_dp_batch_giveups(alfa_dp_batch*, int64_t* n_fast);
 double  alfa_dp_batch_kernel_ms(const alfa_dp_batch*);   /* HIP-event time of the last launch's kernels (after fetch/sync) */
 void    alfa_dp_batch_free(alfa_dp_batch*);
 
@@ -211,6 +214,29 @@ int     alfa_set_lazy_join(int device, int on);
 /* HIP-event stopwatch on that same stream: start, (launch...), stop -> elapsed device milliseconds */
 int     alfa_timer_start(int device);
 int     alfa_timer_stop(int device, double* ms);
+
+/* --- ksw_global for callers that cannot allocate ---------------------------------------------------------
+ * NO counterpart in the reference.  For callers that cannot call hipMalloc or any other allocating routine: code
+ * under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same results as
+ * alfa_ksw_global_batch (same kernels: the wave-per-task fill + tiled backtrack), but every pointer below except `p`
+ * is a DEVICE pointer on `device` and nothing is allocated, copied to the host or synchronised: the call only
+ * enqueues kernels on `stream` (a hipStream_t; NULL = the default stream) and returns.
+ *   d_tasks[i]   qoff/toff = byte offsets of the nt4 query/target of task i in d_seq; w = band
+ *   d_score[i]   ksw_global's return value
+ *   d_cigar      n slots of cig_stride words; the CIGAR of task i (BAM encoding, forward order) is the LAST
+ *                d_n_cigar[i] words of slot i: d_cigar[i*cig_stride + cig_stride - d_n_cigar[i] .. i*cig_stride + cig_stride)
+ *   d_n_cigar[i] number of CIGAR operations; -1 when tlen > qlen + w (the reference indexes outside its matrix there,
+ *                as alfa_ksw_global_batch); -2 (and score INT32_MIN) for a task outside this entry point's envelope:
+ *                qlen < 1, tlen < 1, tlen > max_tlen, 2*min(w, max(qlen,tlen))+1 > 256 or qlen+tlen+2 > cig_stride
+ * What the allocating entry point allocates per batch (parameters, internal task records, direction bytes) lives in
+ * one fixed device array of ALFA_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends.  Limit, checked on the
+ * host: 256 + roundup(64*n, 256) + 256*n*max_tlen <= ALFA_NOALLOC_SCRATCH_BYTES, else ALFA_EINVAL (split the batch).
+ * Every call on a GPU uses that GPU's one array: calls that overlap in time on the same GPU (different streams or
+ * threads) race; calls on one stream are ordered.  Sets the current device to `device`. */
+#define ALFA_NOALLOC_SCRATCH_BYTES (32u << 20)
+typedef struct { int64_t qoff, toff; int32_t qlen, tlen, w, pad; } alfa_dev_task;
+int  alfa_ksw_global_noalloc(const alfa_dp_params* p, const alfa_dev_task* d_tasks, int n, int max_tlen, const uint8_t* d_seq,
+                             int32_t* d_score, uint32_t* d_cigar, int32_t* d_n_cigar, int cig_stride, int device, void* stream);
 
 /* --- misc --------------------------------------------------------------- */
 void        alfa_free(void*);            /* every library-allocated host buffer */
