@@ -51,9 +51,10 @@ def test_noalloc_matches_allocating_entry_point_twice(gpu):
     P = ffi.default_params()
     # first call: mapper-like long-read gaps and windows; second call: fewer, smaller tasks on the same scratch array
     pairs, ws, _ = dpgen.mapper_like_tasks(11, 500, 700, 0.05, 60)
-    keep = [i for i, (q, t) in enumerate(pairs) if len(q) >= 1 and len(t) >= 1 and 2 * min(ws[i], max(len(q), len(t))) + 1 <= 256]
+    keep = [i for i, (q, t) in enumerate(pairs) if len(q) >= 1 and 1 <= len(t) <= 300 and 2 * min(ws[i], max(len(q), len(t))) + 1 <= 256]
+    keep = keep[:(ffi.NOALLOC_SCRATCH_BYTES - 4096) // (64 + 256 * 300)]      # the documented limit of one call
     pairs1, ws1 = [pairs[i] for i in keep], [ws[i] for i in keep]
-    assert _check(P, pairs1, ws1) > 100
+    assert _check(P, pairs1, ws1) > 50
     pairs, ws, _ = dpgen.random_tasks(3, 300)
     keep = [i for i, (q, t) in enumerate(pairs) if 1 <= len(q) and 1 <= len(t) <= 120 and 2 * min(ws[i], max(len(q), len(t))) + 1 <= 256]
     pairs2, ws2 = [pairs[i] for i in keep][:150], [ws[i] for i in keep][:150]
