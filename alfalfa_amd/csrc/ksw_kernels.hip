@@ -1339,6 +1339,7 @@ struct alfa_dp_batch {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool launched = false;
     double kernel_ms = 0;
+    const alfa::Ctx* owner = nullptr;   // launch and fetch are ordered on the creating thread's streams: other threads are refused
 };
 
 namespace {
@@ -1861,6 +1862,7 @@ int alfa_dp_batch_create(int mode, const alfa_dp_params* p, const alfa_dp_task* 
     if (rc) return rc;
     alfa_dp_batch* b = new alfa_dp_batch();
     if ((rc = fill_batch(b, cx, mode, p, t, nullptr, n))) { release_batch(b); delete b; return rc; }
+    b->owner = cx;
     *out = b;
     return ALFA_OK;
 }
@@ -1869,6 +1871,7 @@ int alfa_dp_batch_launch(alfa_dp_batch* b) {
     Ctx* cx;
     int rc = current_ctx(&cx, b->device);
     if (rc) return rc;
+    if (cx != b->owner) return alfa::fail(ALFA_EINVAL, "a resident DP batch must be launched and fetched by the host thread that created it");
     return launch_batch(b, cx);
 }
 int alfa_dp_batch_fetch(alfa_dp_batch* b, void* out, uint32_t** cigar, int32_t* n_cigar, int64_t* cig_off) {
@@ -1877,6 +1880,7 @@ int alfa_dp_batch_fetch(alfa_dp_batch* b, void* out, uint32_t** cigar, int32_t* 
     Ctx* cx;
     int rc = current_ctx(&cx, b->device);
     if (rc) return rc;
+    if (cx != b->owner) return alfa::fail(ALFA_EINVAL, "a resident DP batch must be launched and fetched by the host thread that created it");
     std::vector<std::vector<uint32_t>> cigs;
     if (b->mode == MODE_GLOBAL) cigs.resize((size_t)b->n);
     if ((rc = fetch_batch(b, cx, out, nullptr, b->mode == MODE_GLOBAL ? &cigs : nullptr, n_cigar))) return rc;

@@ -41,6 +41,7 @@ struct alfa_index {
     int device = 0;
     int64_t N = 0, n = 0, K = 1, logN = 0, NKm1 = 0, nM = 0;
     int has_child = 0, has_suflink = 0, has_kmer = 0;
+    uint8_t nul_sub = 0;     // a byte value that occurs nowhere in S (and is not 0): what a NUL inside a read is packed as
     alfa::DevBuf S, SA, LCP, Midx, Mval, CHILD, KMR, KMR2, KBIT, ISA;
 };
 
@@ -1514,11 +1515,24 @@ int alfa_index_upload(const alfa_index_view* v, int device, alfa_index** out) {
         alfa_index_free(ix);
         return rc;
     }
+    {
+        // A NUL byte inside a read matches no text character in the reference (it only ever compares P[x] with S[y]), but the
+        // kernels' chunked compares would take it for the NUL padding behind the text: reads are packed with their NULs replaced
+        // by a byte value that occurs nowhere in S, which is equivalent for every comparison the algorithms make.
+        bool seen[256] = {};
+        for (int64_t i = 0; i < v->N; ++i) seen[v->S[i]] = true;
+        for (int c = 1; c < 256 && !ix->nul_sub; ++c)
+            if (!seen[c] && c != 'a' && c != 'c' && c != 'g' && c != 't') ix->nul_sub = (uint8_t)c;
+    }
     if (ix->has_kmer) {
         // device-side companions of the 10-mer table (layout is ours; content is a function of KMR and SA only)
         std::vector<uint32_t> k2(4 * (size_t)TABLE), kb(TABLE / 32, 0u);
         for (size_t i = 0; i < TABLE; ++i) {
             const uint32_t l = v->KMR[2 * i], r = v->KMR[2 * i + 1];
+            if (r > 0 && (l > r || r >= (uint64_t)v->n)) {
+                alfa_index_free(ix);
+                return alfa::fail(ALFA_EINVAL, "10-mer table entry outside the suffix array (left <= right < n violated)");
+            }
             const uint32_t sa = (l < (uint64_t)v->n) ? v->SA[l] : 0u;
             uint32_t nxt = 0;        // one suffix: S[sa+10 .. sa+13] (the host S carries 16 NUL bytes behind N); more: SA[left+1]
             if (r > l) nxt = (l + 1 < (uint64_t)v->n) ? v->SA[l + 1] : 0u;
@@ -1564,6 +1578,7 @@ struct alfa_seed_plan {
     bool lds_tab = true;    // SMEM: tables fit in LDS
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool launched = false;
+    const alfa::Ctx* owner = nullptr;   // launch and fetch are ordered on the creating thread's stream: other threads are refused
 };
 
 namespace {
@@ -1639,7 +1654,14 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
         max_w = std::max(max_w, w);
         if (smem_like) scr_ints += (int64_t)SMEM_TABLES * w;
         total_pref += np;
-        if (q[i].plen) memcpy(hp + po, q[i].P, (size_t)q[i].plen);
+        if (q[i].plen) {
+            memcpy(hp + po, q[i].P, (size_t)q[i].plen);
+            if (memchr(q[i].P, 0, (size_t)q[i].plen)) {
+                if (!ix->nul_sub) return alfa::fail(ALFA_EINVAL, "a read contains a NUL byte and the text uses every other byte value");
+                for (int j = 0; j < q[i].plen; ++j)
+                    if (!hp[po + j]) hp[po + j] = ix->nul_sub;
+            }
+        }
         po += (size_t)q[i].plen;
     }
     pl->total_pref = total_pref;
@@ -1807,6 +1829,7 @@ int alfa_seed_plan_create(alfa_index* ix, int mem_type, const alfa_seed_query* q
     alfa_seed_plan* pl = new alfa_seed_plan();
     int rc = plan_fill(pl, cx, ix, mem_type, q, nq);
     if (rc) { plan_release(pl); delete pl; return rc; }
+    pl->owner = cx;
     *out = pl;
     return ALFA_OK;
 }
@@ -1814,12 +1837,14 @@ int alfa_seed_plan_launch(alfa_seed_plan* pl) {
     if (!pl) return alfa::fail(ALFA_EINVAL, "null plan");
     alfa::Ctx* cx = alfa::thread_ctx(pl->ix->device);
     if (!cx) return ALFA_ENODEV;
+    if (cx != pl->owner) return alfa::fail(ALFA_EINVAL, "a resident seed plan must be launched and fetched by the host thread that created it");
     return plan_launch(pl, cx);
 }
 int alfa_seed_plan_fetch(alfa_seed_plan* pl, alfa_match** matches, int64_t* offsets) {
     if (!pl || !matches || !offsets) return alfa::fail(ALFA_EINVAL, "null argument");
     alfa::Ctx* cx = alfa::thread_ctx(pl->ix->device);
     if (!cx) return ALFA_ENODEV;
+    if (cx != pl->owner) return alfa::fail(ALFA_EINVAL, "a resident seed plan must be launched and fetched by the host thread that created it");
     return plan_fetch(pl, cx, matches, offsets);
 }
 int64_t alfa_seed_plan_queries(const alfa_seed_plan* pl) { return pl ? pl->total_pref : 0; }

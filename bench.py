@@ -10,7 +10,14 @@ torch.cuda.synchronize() + alfa_sync() on both sides.
 
 Workload = BASELINE.json configs[2] ("synthetic 5 Mbp random reference, 1M simulated 250 bp reads at
 2% error, 1 GPU"): the configuration the metric is quoted on that fits one GPU.  configs[0]/[1] are the
-48 kbp lambda-phage walkthrough files (parity cases, not bench lines).
+48 kbp lambda-phage walkthrough files (parity cases, not bench lines).  `--config c4` runs configs[3]
+(100 Mbp reference, 2-10 kbp reads at 10 % error, `-e 0.12`) through the same steps; the driver's default is c3.
+
+What the line says (one reader, one line): `value` = hot-path replay rate (kernels only, inputs resident);
+`mapped_reads_per_s` = the SURVEY 8d figure, FASTQ in -> SAM out through the command line tool; `pcie_inclusive_reads_per_s`
+= create + launch + fetch of one step through the C ABI (host packing, H2D, kernels, D2H, unpacking); `roofline` = the
+seed kernel against HBM; `roofline_dp` = the DP kernels against the int32 VALU peak; `cpu_baseline` = the compiled
+reference on this box's usable host cores (count stated), run at the same thread count as the GPU tool.
 
 DP tasks are the real ones: before the timed region the product command line tool (alfalfa_amd align = staged host
 mapper + HIP hot path, byte-identical SAM to the reference) maps each step's reads once with ALFA_TASK_LOG set and
@@ -78,7 +85,28 @@ def simulate_batch(rng, ref, n, rlen, err):
 TASK_DTYPE = np.dtype([("query", "<u8"), ("target", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("h0", "<i4")])
 
 
-def mapper_dp_tasks(workdir, index_prefix, reads, threads=8, device=0):
+def usable_cores():
+    """host cores this process may use: the affinity mask, capped by OMP_NUM_THREADS when the box sets it (a GPU box shows
+    the whole machine in os.cpu_count() but gives a one-GPU job a share of it)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        n = min(n, int(os.environ.get("OMP_NUM_THREADS", n)))
+    except ValueError:
+        pass
+    return max(1, n)
+
+
+def simulate_long(rng, ref_bytes, n, lo, hi, err):
+    """n reads of length U[lo,hi] with per-base error err (60/20/20), 50/50 strand: (as sequenced, reverse complements)"""
+    import seqgen
+    fw = seqgen.sim_reads(rng, ref_bytes, n, lo, hi, err)
+    return fw, [seqgen.revcomp(r) for r in fw]
+
+
+def mapper_dp_tasks(workdir, index_prefix, reads, threads=8, device=0, extra=()):
     """The DP task stream the staged host mapper really issues for `reads`: run the product command line tool
     (alfalfa_amd align, HIP hot path) once with ALFA_TASK_LOG set and load every ksw_extend / ksw_nw / ksw_global
     task it submitted.  Returns {kind: (ctypes DpTask array, keepalive)} for kind in extend/nw/global."""
@@ -95,7 +123,7 @@ def mapper_dp_tasks(workdir, index_prefix, reads, threads=8, device=0):
     exe = os.path.join(ROOT, "alfalfa_amd", "alfalfa_amd")
     env = dict(os.environ, ALFA_TASK_LOG=prefix)
     subprocess.run([exe, "align", "-i", index_prefix, "-0", fq, "-o", os.path.join(workdir, "step.sam"), "-t", str(threads),
-                    "--device", str(device)],
+                    "--device", str(device)] + list(extra),
                    check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     hdrs, seqs = [], []
     for hf in sorted(glob.glob(prefix + ".*.hdr")):
@@ -162,19 +190,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=100000, help="reads per step per GPU")
-    ap.add_argument("--ref-len", type=int, default=5000000)
+    ap.add_argument("--config", default="c3", choices=["c3", "c4"], help="BASELINE configs[2] (default) or configs[3]")
+    ap.add_argument("--batch", type=int, default=0, help="reads per step per GPU (default 100000 for c3, 4000 for c4)")
+    ap.add_argument("--ref-len", type=int, default=0)
     ap.add_argument("--read-len", type=int, default=250)
     ap.add_argument("--err", type=float, default=0.02)
     ap.add_argument("--sparseness", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20000)
-    ap.add_argument("--e2e-reads", type=int, default=1000000, help="reads for the end-to-end command line comparison (0 = skip)")
-    ap.add_argument("--e2e-threads", type=int, default=16)
+    ap.add_argument("--e2e-reads", type=int, default=-1, help="reads for the end-to-end command line comparison (0 = skip; default 1000000 for c3, 20000 for c4)")
+    ap.add_argument("--e2e-threads", type=int, default=0, help="threads of both command line tools (default: min(usable host cores, 214))")
     ap.add_argument("--align-tasks", type=int, default=50000, help="mate-rescue shaped ksw_align tasks for the informative ksw_align section")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for --dist-selftest)")
     ap.add_argument("--dist-selftest", action="store_true", help="CPU rehearsal of the multi-rank control flow, no GPU work")
     args = ap.parse_args()
+    c4 = args.config == "c4"
+    args.batch = args.batch or (4000 if c4 else 100000)
+    args.ref_len = args.ref_len or (100000000 if c4 else 5000000)
+    if c4:
+        args.err = 0.10
+    if args.e2e_reads < 0:
+        args.e2e_reads = 20000 if c4 else 1000000
+    cores = usable_cores()
+    if args.e2e_threads <= 0:
+        args.e2e_threads = min(cores, 214)       # reference: bpCount = threads * 10^7 is an int (src/main.cpp:116)
+    cli_extra = ["-e", "0.12"] if c4 else []     # the default 0.08 sends most 10 %-error reads through rescue
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -197,7 +237,7 @@ def main():
     from alfalfa_amd import ffi
     import seqgen
     K = args.sparseness
-    ref = make_reference(args.ref_len, 1)        # PRNG seed 1 for C3
+    ref = make_reference(args.ref_len, 2 if c4 else 1)        # PRNG seed 1 for C3, 2 for C4
     ref_bytes = ref.tobytes()
     ref_nt4 = NT4[ref]
     t0 = time.time()
@@ -209,25 +249,33 @@ def main():
     index_prefix = os.path.join(workdir, "idx")
     hidx.save(index_prefix)
 
-    err_percent = 0.08                           # reference default (src/options.cpp:52)
+    err_percent = 0.13 if c4 else 0.08           # reference default 0.08 (src/options.cpp:52); -e X stores X + 0.01 (:296)
     min_len, sparse_q = seqgen.seed_params(K, args.read_len, err_percent)
-    edit_dist = int(err_percent * args.read_len) + 1
+
+    def seed_queries(reads):
+        if not c4:
+            return ffi.make_seed_queries(reads, min_len, 10000, sparse_q)
+        prm = [seqgen.seed_params(K, len(r), err_percent) for r in reads]     # min_len grows with the read length (src/mapper.cpp:1226)
+        return ffi.make_seed_queries(reads, [a for a, _ in prm], 10000, [b for _, b in prm])
     P = ffi.default_params()
     nsteps = args.warmup + args.steps
     rng = rank_rng(rank)
     steps = []
     sample = None
     for s in range(nsteps):
-        fw, rc, pos, strand = simulate_batch(rng, ref, args.batch, args.read_len, args.err)
-        queries = ffi.make_seed_queries(fw + rc, min_len, 10000, sparse_q)
+        if c4:
+            fw, rc = simulate_long(rng, ref_bytes, args.batch, 2000, 10000, args.err)
+        else:
+            fw, rc, pos, strand = simulate_batch(rng, ref, args.batch, args.read_len, args.err)
+        queries = seed_queries(fw + rc)
         plan = ffi.SeedPlan(didx, ffi.SEED_SMAM, queries)
-        tk = mapper_dp_tasks(workdir, index_prefix, fw, threads=8, device=dev)
+        tk = mapper_dp_tasks(workdir, index_prefix, fw, threads=8, device=dev, extra=cli_extra)
         (te, ke), (tn, kn), (tg, kg) = tk["extend"], tk["nw"], tk["global"]
         b_ext = ffi.DpBatch(ffi.DP_EXTEND, P, te, dev)
         b_nw = ffi.DpBatch(ffi.DP_NW, P, tn, dev)
         b_gl = ffi.DpBatch(ffi.DP_GLOBAL, P, tg, dev)
         steps.append((plan, b_ext, b_nw, b_gl))
-        if s == 0:
+        if s == args.warmup:                      # the first TIMED step: its results are the ones checked against the oracle
             sample = (fw, rc, te, tn, tg, (ke, kn, kg))
         else:
             del fw, rc
@@ -295,9 +343,32 @@ def main():
     cells_gl = sum(st[3].cells for st in timed)
     queries_per_step = timed[0][0].queries
 
-    # correctness spot check of one timed step against nothing but itself being fetched (parity lives in tests/)
+    # results of one TIMED step are fetched (and a sample of them compared with the oracle below, on rank 0)
     m, off = timed[0][0].fetch()
     seeds_per_read = len(m) / args.batch
+    timed_ext = timed[0][1].fetch()
+    timed_nw = timed[0][2].fetch()
+    timed_gl = timed[0][3].fetch()
+    fast_tasks = {"extend": timed[0][1].giveups(), "nw": timed[0][2].giveups(), "global": timed[0][3].giveups()}
+
+    # PCIe-inclusive rate: create (host packing + H2D) + launch + fetch (D2H + unpacking) of the first step, through the
+    # synchronous halves of the C ABI.  Never `value`.
+    fw0, rc0, te0, tn0, tg0, _k0 = sample
+    tp0 = time.perf_counter()
+    pl = ffi.SeedPlan(didx, ffi.SEED_SMAM, seed_queries(fw0 + rc0))
+    pl.launch()
+    pcie_m, _pcie_off = pl.fetch()
+    tp1 = time.perf_counter()
+    for mode, tk_ in ((ffi.DP_NW, tn0), (ffi.DP_EXTEND, te0), (ffi.DP_GLOBAL, tg0)):
+        bb = ffi.DpBatch(mode, P, tk_, dev)
+        bb.launch()
+        bb.fetch()
+        del bb
+    tp2 = time.perf_counter()
+    del pl
+    pcie = {"reads_per_s": args.batch / (tp2 - tp0), "seed_s": tp1 - tp0, "dp_s": tp2 - tp1,
+            "note": "one step through create + launch + fetch (host packing, H2D, kernels, D2H, unpacking; python ctypes marshalling of "
+                    "the query/task arrays is outside); dominated by host packing"}
 
     if rank != 0:
         if world > 1:
@@ -309,7 +380,7 @@ def main():
     fw, rc, te, tn, tg, _keep = sample
     ns = min(2000, len(fw))
     O.orc_counters_reset()
-    qs = ffi.make_seed_queries(fw[:ns] + rc[:ns], min_len, 10000, sparse_q)
+    qs = seed_queries(fw[:ns] + rc[:ns])
     O.orc_seed_batch(hidx.view, ffi.SEED_SMAM, qs)
     c = O.orc_counters()
     bytes_per_read = c["sa_bytes"] / ns
@@ -330,11 +401,31 @@ def main():
         traffic = None
 
     cpu = None
+    executed_ratio = None
+    # ---- a sample of the TIMED step's DP results against the oracle (the timed launches are the ones checked)
+    nchk = 3000
+    chk = {}
+    if len(te) and len(tn) and len(tg):
+        ke, kn, kg = min(nchk, len(te)), min(nchk, len(tn)), min(nchk, len(tg))
+        chk["extend"] = bool(np.array_equal(timed_ext[:ke], O.orc_ksw_extend_batch(P, (ffi.DpTask * ke).from_address(C_addr(te)))))
+        chk["nw"] = bool(np.array_equal(timed_nw[:kn], O.orc_ksw_nw_batch(P, (ffi.DpTask * kn).from_address(C_addr(tn)))))
+        so, co, no_, oo = O.orc_ksw_global_batch(P, (ffi.DpTask * kg).from_address(C_addr(tg)))
+        sg, cg, ng, og = timed_gl
+        okg = np.array_equal(sg[:kg], so) and np.array_equal(ng[:kg], no_)
+        for i in range(kg if okg else 0):
+            if ng[i] > 0 and not np.array_equal(cg[og[i]:og[i] + ng[i]], co[oo[i]:oo[i] + no_[i]]):
+                okg = False
+                break
+        chk["global"] = bool(okg)
+    mo, oo_ = O.orc_seed_batch(hidx.view, ffi.SEED_SMAM, seed_queries(fw[:500] + rc[:500])) if not c4 else (None, None)
+    if mo is not None:
+        # the plan seeds fw[0..n) then rc[0..n): reads 0..499 are the first 500 queries
+        chk["seeds_fw500"] = bool(np.array_equal(off[:501], oo_[:501]) and np.array_equal(m[:int(off[500])], mo[:int(oo_[500])]))
     if not args.no_cpu_baseline and world == 1:      # the CPU legs run at N=1 only
         # the oracle (scalar port) on one host core over a bounded sample of the same workload
         nsamp = min(args.cpu_sample, len(fw))
         frac = nsamp / len(fw)
-        qs = ffi.make_seed_queries(fw[:nsamp] + rc[:nsamp], min_len, 10000, sparse_q)
+        qs = seed_queries(fw[:nsamp] + rc[:nsamp])
         ne, nn, ng = int(len(te) * frac), int(len(tn) * frac), int(len(tg) * frac)
         tc0 = time.perf_counter()
         O.orc_seed_batch(hidx.view, ffi.SEED_SMAM, qs)
@@ -346,6 +437,10 @@ def main():
         tcpu = time.perf_counter() - tc0
         cc = O.orc_counters()
         cpu_cells = cc["cells_extend"] + cc["cells_nw"] + cc["cells_global"]
+        # ksw_extend cells: SURVEY 8d counts the inner-loop iterations the reference executes; the GCUPS below divide the
+        # static band envelope (what the kernels compute).  Their ratio on this sample:
+        env_ext = ffi.DpBatch(ffi.DP_EXTEND, P, (ffi.DpTask * ne).from_address(C_addr(te)), dev).cells if ne else 0
+        executed_ratio = cc["cells_extend"] / env_ext if env_ext else None
         cpu = {"value": nsamp / tcpu, "unit": "reads/s", "cores": 1, "kind": "port",
                "sample": "%d reads (both strands seeded + their DP tasks) of step 0, oracle/liboracle.so, 1 thread" % nsamp,
                "seed_reads_per_s": nsamp / tseed, "dp_gcups": cpu_cells / max(tcpu - tseed, 1e-9) / 1e9}
@@ -356,7 +451,10 @@ def main():
     if args.e2e_reads > 0 and world == 1:
         import hashlib
         import subprocess
-        er, _, _, _ = simulate_batch(np.random.default_rng(77), ref, args.e2e_reads, args.read_len, args.err)
+        if c4:
+            er, _ = simulate_long(np.random.default_rng(77), ref_bytes, args.e2e_reads, 2000, 10000, args.err)
+        else:
+            er, _, _, _ = simulate_batch(np.random.default_rng(77), ref, args.e2e_reads, args.read_len, args.err)
         fq = os.path.join(workdir, "e2e.fq")
         with open(fq, "w") as f:
             for i, r in enumerate(er):
@@ -368,7 +466,7 @@ def main():
                 continue
             outp = os.path.join(workdir, name + ".sam")
             tt = time.perf_counter()
-            pr = subprocess.run([exe, "align", "-i", index_prefix, "-0", fq, "-o", outp, "-t", str(args.e2e_threads)],
+            pr = subprocess.run([exe, "align", "-i", index_prefix, "-0", fq, "-o", outp, "-t", str(args.e2e_threads)] + cli_extra,
                                 stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             dt = time.perf_counter() - tt
             body = b"\n".join(l for l in open(outp, "rb").read().split(b"\n") if not l.startswith(b"@PG"))
@@ -382,6 +480,7 @@ def main():
     if e2e and e2e.get("reference_cpu", {}).get("rc") == 0:
         port = cpu
         cpu = {"value": e2e["reference_cpu"]["reads_per_s"], "unit": "reads/s", "cores": args.e2e_threads, "kind": "reference",
+               "host_cores_usable": cores, "host_cpu_count": os.cpu_count(),
                "sample": "%d reads of the same workload through the compiled reference (oracle/_ref/alfalfa align -t %d), whole command "
                          "line FASTQ -> SAM, %.1f s wall" % (args.e2e_reads, args.e2e_threads, e2e["reference_cpu"]["seconds"]),
                "hot_path_port_1core": port}
@@ -424,9 +523,43 @@ def main():
     except Exception as e:  # informative section: never fails the bench line
         align = {"error": str(e)}
     dp_ms = sum(ext_ms) + sum(nw_ms) + sum(gl_ms)
+
+    def dp_roof(cells, ms, ops):
+        g = cells / max(ms, 1e-9) / 1e6
+        return {"gcups": g, "ops_per_cell": ops, "achieved": g * ops / 1e3, "frac": g * ops / 1e3 / VALU_PEAK_TOPS}
+    roofline_dp = {
+        "bound": "valu", "peak": VALU_PEAK_TOPS, "unit": "T int32 lane-op/s",
+        "peak_note": "256 CU x 4 SIMD-32 x 2.4 GHz; algorithmic ops per cell from SURVEY 8d (12 / 8 / 16)",
+        "kernels": "ksw_lane2_kernel<MODE> (band in registers, G skewed lanes per task: the short-read stream); ksw_wave_kernel / "
+                   "ksw_group_kernel (+ backtrack kernels) for bands beyond 64 diagonals, irregular tasks and give-ups",
+        "extend": dp_roof(cells_ext, sum(ext_ms), 12), "nw": dp_roof(cells_nw, sum(nw_ms), 8), "global": dp_roof(cells_gl, sum(gl_ms), 16),
+        "cells": "static band envelope sum_i (min(i+w+1,qlen) - max(i-w,0)), what the kernels compute; the reference's executed "
+                 "inner-loop iterations of ksw_extend (SURVEY 8d) are executed_over_envelope x that (oracle counter on the CPU sample)",
+        "extend_executed_over_envelope": executed_ratio,
+        "band_in_registers_tasks_and_giveups": fast_tasks,
+        "timing": "each batch of the timed steps launched once more by itself, HIP events around its kernels",
+    }
+    occupancy = None
+    try:
+        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_seed_limiter.json"))
+        if prof:
+            occupancy = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
+    except Exception:
+        occupancy = None
+    e2e_gpu = (e2e or {}).get("alfalfa_amd_gpu", {})
     out = {
         "metric": "mapped reads/sec (hot path: SMAM seeds both strands + banded DP) + banded-DP GCUPS",
         "value": whole_job_value(args.batch, args.steps, world, elapsed),
+        "value_is": "hot-path replay: kernel launches over batches already packed and resident in HBM (no H2D of reads/tasks, no "
+                    "D2H of results, no host chaining between DP rounds); NOT comparable with cpu_baseline, which is a whole "
+                    "command line -- compare mapped_reads_per_s with cpu_baseline.value",
+        "mapped_reads_per_s": e2e_gpu.get("reads_per_s"),
+        "mapped_reads_per_s_is": "SURVEY 8d: FASTQ in -> SAM out through alfalfa_amd align -t %d (index load and HIP start-up included), "
+                                 "SAM identical to the reference: %s" % (args.e2e_threads, (e2e or {}).get("sam_identical")),
+        "pcie_inclusive_reads_per_s": pcie["reads_per_s"],
+        "pcie_inclusive": pcie,
+        "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+        "timed_step_parity_vs_oracle": chk,
         "unit": "reads/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -438,10 +571,14 @@ def main():
         "dtype": "u8/int32",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[2]: %d bp iid random reference, %d-bp reads at %.0f%% error (60/20/20 sub/ins/del), "
-                        "index sparseness K=%d, %d reads per step per GPU, %d timed steps" %
-                        (args.ref_len, args.read_len, args.err * 100, K, args.batch, args.steps),
-            "seed_type": "SMAM (CLI --seed SMEM default), min_len=%d sparseQ=%d maxCount=10000, fw+rc" % (min_len, sparse_q),
+            "workload": ("BASELINE configs[3]: %d bp iid random reference, 2-10 kbp reads at %.0f%% error (60/20/20 sub/ins/del), -e 0.12, "
+                         "index sparseness K=%d, %d reads per step per GPU, %d timed steps" % (args.ref_len, args.err * 100, K, args.batch, args.steps))
+                        if c4 else
+                        ("BASELINE configs[2]: %d bp iid random reference, %d-bp reads at %.0f%% error (60/20/20 sub/ins/del), "
+                         "index sparseness K=%d, %d reads per step per GPU, %d timed steps" %
+                         (args.ref_len, args.read_len, args.err * 100, K, args.batch, args.steps)),
+            "seed_type": ("SMAM (CLI --seed SMEM default), min_len and sparseQ per read length (src/mapper.cpp:1226, :533), maxCount=10000, fw+rc"
+                          if c4 else "SMAM (CLI --seed SMEM default), min_len=%d sparseQ=%d maxCount=10000, fw+rc" % (min_len, sparse_q)),
             "dp_tasks": "every ksw_extend/ksw_nw/ksw_global task the staged host mapper (alfalfa_amd align) issues for the step's "
                         "reads, captured before the timed region and replayed resident; %.2f/%.2f/%.2f tasks per read" %
                         (len(timed[0][1]._tasks) / args.batch, len(timed[0][2]._tasks) / args.batch, len(timed[0][3]._tasks) / args.batch),
@@ -457,14 +594,17 @@ def main():
             "extend": {"cells": cells_ext, "ms": sum(ext_ms), "gcups": cells_ext / max(sum(ext_ms), 1e-9) / 1e6},
             "nw": {"cells": cells_nw, "ms": sum(nw_ms), "gcups": cells_nw / max(sum(nw_ms), 1e-9) / 1e6},
             "global": {"cells": cells_gl, "ms": sum(gl_ms), "gcups": cells_gl / max(sum(gl_ms), 1e-9) / 1e6},
-            "valu_frac_extend": cells_ext * 12 / max(sum(ext_ms) * 1e-3, 1e-12) / 1e12 / VALU_PEAK_TOPS,
         },
+        "roofline_dp": roofline_dp,
         "seed_queries_per_step": queries_per_step,
         "seeds_per_read": seeds_per_read,
         "index_build_s": t_index,
         "roofline": {
             "kernel": "smam_count_kernel",
             "bound": "hbm",
+            "limiter": "latency / instruction issue, not bandwidth: a gather kernel (FETCH_SIZE = algorithmic bytes, L2 hit rate "
+                       "and wave wait fraction in profiles/*_seed_limiter.json)",
+            "limiter_counters": occupancy,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

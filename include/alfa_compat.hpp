@@ -30,7 +30,7 @@ struct match_t {
 inline void fill_params(alfa_dp_params& p, int m, const int8_t* mat, int gapo, int gape, int zdrop) {
     std::memset(&p, 0, sizeof(p));
     p.m = m;
-    std::memcpy(p.mat, mat, (size_t)m * m);
+    if (m >= 1 && m <= 8) std::memcpy(p.mat, mat, (size_t)m * m);     // the library rejects m outside 1..8 (mat holds 64 entries)
     p.gapo = gapo; p.gape = gape; p.zdrop = zdrop;
 }
 inline void must(int rc) {

@@ -180,7 +180,12 @@ int  alfa_dp_band_batch(int variant, const alfa_dpband_scores* s, const alfa_dpb
  * that device (asynchronous, no allocation, no host synchronisation) and fetch() waits,
  * copies the results back and unpacks them exactly like the synchronous call.
  * No counterpart in the reference (it has no device); semantics are those of the
- * corresponding synchronous call. */
+ * corresponding synchronous call.
+ * Threading: a batch / plan belongs to the host thread that created it -- create, launch and fetch are ordered on that
+ * thread's streams, so launch and fetch from any other thread are refused with ALFA_EINVAL (free may come from any thread
+ * once the owner has fetched or synchronised).  Different threads work on different objects concurrently.  Launching an
+ * object again before the previous launch has been fetched or synchronised (possible with alfa_set_lazy_join) overwrites
+ * results that are still being produced: synchronise first. */
 typedef struct alfa_dp_batch alfa_dp_batch;
 #define ALFA_DP_NW     0
 #define ALFA_DP_GLOBAL 1

@@ -186,3 +186,56 @@ def test_smam_read_bytes_of_every_kind(gpu):
         reads.append(bytes(ref[1000:1000 + plen]))
     assert _check(hidx, didx, reads, 20, 10000, 1) > 150
     _check(hidx, didx, reads, 40, 10000, 2)
+
+
+def test_reads_with_nul_bytes(gpu):
+    """a NUL inside a read matches no text character (reference semantics, pinned against the compiled reference in
+    tests/test_oracle_vs_golden.py); the kernels' NUL-padded chunk compares must not mistake it for the end of the text"""
+    import seqgen
+    from test_oracle_vs_golden import _odd_byte_reads
+    rng = np.random.default_rng(5)
+    ref = seqgen.rand_ref(rng, 30000)
+    reads = _odd_byte_reads(rng, ref, 200) + [b"\x00" * 50, b"acgt" * 10 + b"\x00" + b"acgt" * 10]
+    for K in (1, 12):
+        hidx = ffi.HostIndex.build_mem(["x"], [ref], K=K)
+        didx = ffi.DeviceIndex(hidx, 0)
+        for mt in (ffi.SEED_SMAM, ffi.SEED_MEM, ffi.SEED_SMEM):
+            q = ffi.make_seed_queries(reads, 30, 1000, 1, 10)
+            m, off = didx.seed_batch(mt, q)
+            mo, oo = O.orc_seed_batch(hidx.view, mt, q)
+            assert np.array_equal(off, oo) and np.array_equal(m, mo), (K, mt)
+
+
+def test_resident_objects_belong_to_their_thread(gpu):
+    """launch / fetch of a resident plan or batch from another host thread is refused (they are ordered on the creator's streams)"""
+    import threading
+    import seqgen
+    rng = np.random.default_rng(9)
+    ref = seqgen.rand_ref(rng, 20000)
+    hidx = ffi.HostIndex.build_mem(["x"], [ref], K=12)
+    didx = ffi.DeviceIndex(hidx, 0)
+    reads = seqgen.sim_reads(rng, ref, 20, 100, 200, 0.02)
+    plan = ffi.SeedPlan(didx, ffi.SEED_SMAM, ffi.make_seed_queries(reads, 30, 1000, 1))
+    P = ffi.default_params()
+    a = rng.integers(0, 4, 40).astype(np.uint8)
+    tasks, keep = ffi.make_dp_tasks([(a, a.copy())] * 8, 5, 0)
+    batch = ffi.DpBatch(ffi.DP_NW, P, tasks, 0)
+    errs = []
+
+    def other():
+        for fn in (plan.launch, plan.fetch, batch.launch, batch.fetch):
+            try:
+                fn()
+                errs.append("accepted")
+            except ffi.AlfaError as e:
+                errs.append(str(e))
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert len(errs) == 4 and all("thread that created it" in e for e in errs), errs
+    plan.launch()
+    batch.launch()
+    m, off = plan.fetch()
+    assert np.array_equal(batch.fetch(), np.full(8, 40, np.int32))
+    mo, oo = O.orc_seed_batch(hidx.view, ffi.SEED_SMAM, ffi.make_seed_queries(reads, 30, 1000, 1))
+    assert np.array_equal(m, mo)

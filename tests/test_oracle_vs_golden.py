@@ -68,3 +68,31 @@ def test_oracle_ksw_align_vs_live_reference():
             assert tuple(int(v) for v in got[i]) == O.ref_ksw_align(p, q, t, x), (sc, i)
             n += 1
     assert n > 1000
+
+
+def _odd_byte_reads(rng, ref, n):
+    """reads with NUL bytes (and other non-ACGT bytes) sprinkled in: a NUL matches no text character in the reference"""
+    import seqgen
+    out = []
+    for r in seqgen.sim_reads(rng, ref, n, 60, 400, 0.02):
+        a = bytearray(r)
+        for p in rng.integers(0, len(a), int(rng.integers(1, 4))):
+            a[int(p)] = int(rng.choice([0, 0, 0, ord("n"), ord("$"), 1]))
+        out.append(bytes(a))
+    return out
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref (compiled reference) only exists in the build container")
+def test_oracle_vs_live_reference_reads_with_nul_bytes():
+    import seqgen
+    rng = np.random.default_rng(5)
+    ref = seqgen.rand_ref(rng, 30000)
+    reads = _odd_byte_reads(rng, ref, 60)
+    for K in (1, 12):
+        mine = ffi.HostIndex.build_mem(["x"], [ref], K=K)
+        rix = O.RefIndex.build_mem(["x"], [ref], K=K)
+        for mt in (0, 1, 2):
+            q = ffi.make_seed_queries(reads, 30, 1000, 1, 10)
+            m, off = O.orc_seed_batch(mine.view, mt, q)
+            for i, r in enumerate(reads):
+                assert np.array_equal(m[off[i]:off[i + 1]], rix.seed(mt, r, 30, 1000, 1, 10)), (K, mt, i)
