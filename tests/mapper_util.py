@@ -196,3 +196,39 @@ def run_synth_single(exe, name, extra=()):
 
 def synth_md5(name):
     return json.load(open(os.path.join(G.GOLD, "sam_synth_md5.json")))[name]
+
+
+# ---- C5-shaped paired long reads at reduced reference size (BASELINE configs[4]: 5 kbp pairs, insert 12 000 +- 2 000,
+# 10 % error, -I 8000 -X 16000 -e 0.12).  Deterministic inputs; the compiled reference's md5 is a fixture
+# (tools/make_c5_goldens.py).
+C5_ARGS = ["-I", "8000", "-X", "16000", "-e", "0.12"]
+
+
+def write_c5_paired(d, n_pairs=150, ref_len=3000000, seed=31):
+    import numpy as np
+    import seqgen
+    rng = np.random.default_rng(seed)
+    ref = seqgen.rand_ref(rng, ref_len)
+    with open(os.path.join(d, "c5.fa"), "w") as f:
+        f.write(">chr1\n")
+        s = ref.decode().upper()
+        for i in range(0, len(s), 60):
+            f.write(s[i:i + 60] + "\n")
+    m1, m2 = seqgen.sim_pairs(rng, ref, n_pairs, 5000, 10000, 14000, 0.10, 0.10, 200)
+    for tag, reads in ((1, m1), (2, m2)):
+        with open(os.path.join(d, "c5_%d.fq" % tag), "w") as f:
+            for i, r in enumerate(reads):
+                f.write("@p%d/%d\n%s\n+\n%s\n" % (i, tag, r.decode().upper(), "I" * len(r)))
+    return "c5.fa", "c5_1.fq", "c5_2.fq"
+
+
+def run_c5_paired(exe, d, threads="4", index_exe=None):
+    pre = os.path.join(d, "c5idx_%s" % os.path.basename(exe))
+    if not os.path.exists(pre + ".aux"):
+        subprocess.run([index_exe or exe, "index", "-r", "c5.fa", "-p", pre, "-s", "12"], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+    out = os.path.join(d, "c5_%s.sam" % os.path.basename(exe))
+    p = subprocess.run([exe, "align", "-i", pre, "-1", "c5_1.fq", "-2", "c5_2.fq", "-o", out, "-t", threads] + C5_ARGS, cwd=d,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return sam_body(out)

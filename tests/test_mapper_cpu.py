@@ -37,3 +37,14 @@ def test_host_mapper_paired_modes_synthetic(name):
 def test_host_mapper_option_sweep_synthetic(name):
     """2 700 synthetic single-end reads (two contigs with repeats, short and long reads): the options that steer the host logic"""
     assert M.md5(M.run_synth_single(M.CPU_EXE, name, ["-t", "8"])) == M.synth_md5(name)
+
+
+@pytest.mark.skipif(not os.path.exists(M.CPU_EXE), reason="tests/_cpu_mapper not built")
+def test_host_mapper_c5_paired_long_reads():
+    """C5-shaped: paired 5 kbp reads, insert 12 000 +- 2 000, 10 % error, -I 8000 -X 16000 -e 0.12 (md5 of the compiled reference's SAM)"""
+    import json
+    import golden_util as G
+    d = G.tmpdir()
+    M.write_c5_paired(d)
+    gold = json.load(open(os.path.join(G.GOLD, "c5_paired_md5.json")))
+    assert M.md5(M.run_c5_paired(M.CPU_EXE, d, threads="8")) == gold["md5"]
