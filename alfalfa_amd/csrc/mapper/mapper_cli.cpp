@@ -13,6 +13,10 @@
 #include <mutex>
 #include <thread>
 #include <chrono>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "../seqio.h"
 
@@ -145,6 +149,99 @@ bool next_read(SeqReader& rd, Read& r) {
     else r.qual = "*";
     if (r.qname.length() > 2 && r.qname[r.qname.length() - 2] == '/') r.qname.erase(r.qname.length() - 2);
     return true;
+}
+
+// ---- parallel FASTQ parse (fastqInputReader::nextRead src/fasta.cpp:135-159 + src/main.cpp:64-92)
+// The reader thread of a plain (not gzip) file only SPLITS records: four memchr calls per record over the memory-mapped
+// file.  Everything the reference's reader does per record -- name up to the first white space, lower-casing, '/1' '/2'
+// stripping, the strings themselves -- happens on the worker that maps the read (materialize()).  The split takes the fast
+// path only for records it can prove kseq would parse the same way: four lines, '@' first, a non-empty sequence line that
+// does not start with '>', '+' or '@', '+' on the third, a quality line exactly as long as the sequence and no '\r' anywhere.
+// The first record that fails a check sends the rest of the file through SeqReader (the kseq restatement), on the reader
+// thread as before; gzip input always takes that path.
+struct RawRec {
+    const char* p = nullptr;      // '@' of the record; nullptr: the Read was filled by the general parser
+    uint32_t l1 = 0, l2 = 0;      // lengths of the header line (with '@') and of the sequence (= quality) line
+    uint32_t o2 = 0, o4 = 0;      // offsets of the sequence and quality lines from p
+};
+
+class ReadSource {
+   public:
+    ~ReadSource() { if (map_ && map_ != MAP_FAILED) munmap((void*)map_, size_); if (fd_ >= 0) ::close(fd_); }
+    bool open(const char* path) {
+        static const bool no_fast = getenv("ALFA_NO_FAST_FASTQ") != nullptr;
+        fd_ = ::open(path, O_RDONLY);
+        struct stat st;
+        if (!no_fast && fd_ >= 0 && fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 2) {
+            size_ = (size_t)st.st_size;
+            map_ = (const char*)mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+            if (map_ != MAP_FAILED && !((unsigned char)map_[0] == 0x1f && (unsigned char)map_[1] == 0x8b)) {
+                (void)madvise((void*)map_, size_, MADV_SEQUENTIAL);
+                fast_ = true;
+                return true;
+            }
+            if (map_ != MAP_FAILED) munmap((void*)map_, size_);
+            map_ = nullptr;
+        }
+        return slow_.open(path);
+    }
+    // 0: end of input; 1: x describes a record (r untouched); 2: r filled by the general parser (x.p == nullptr)
+    int next(Read& r, RawRec& x) {
+        if (fast_) {
+            if (pos_ >= size_) return 0;
+            if (split(x)) return 1;
+            // not provably kseq-equivalent from here on: the general parser takes over at this byte
+            fast_ = false;
+            slow_.open_mem(map_ + pos_, size_ - pos_);
+        }
+        x.p = nullptr;
+        return next_read(slow_, r) ? 2 : 0;
+    }
+   private:
+    bool split(RawRec& x) {
+        const char* b = map_ + pos_;
+        const char* e = map_ + size_;
+        if (*b != '@') return false;
+        const char* n1 = (const char*)memchr(b, '\n', (size_t)(e - b));
+        if (!n1) return false;
+        const char* s2 = n1 + 1;
+        const char* n2 = s2 < e ? (const char*)memchr(s2, '\n', (size_t)(e - s2)) : nullptr;
+        if (!n2 || n2 == s2 || *s2 == '>' || *s2 == '+' || *s2 == '@') return false;
+        const char* s3 = n2 + 1;
+        if (s3 >= e || *s3 != '+') return false;
+        const char* n3 = (const char*)memchr(s3, '\n', (size_t)(e - s3));
+        if (!n3) return false;
+        const char* s4 = n3 + 1;
+        const size_t l2 = (size_t)(n2 - s2);
+        if ((size_t)(e - s4) < l2) return false;
+        const char* n4 = s4 + l2;                       // the quality line must end exactly here
+        if (n4 < e && *n4 != '\n') return false;
+        if (memchr(s4, '\n', l2)) return false;         // ... and not before
+        const size_t reclen = (size_t)(n4 - b);
+        if (memchr(b, '\r', reclen) || reclen >= (1ull << 31)) return false;
+        x.p = b; x.l1 = (uint32_t)(n1 - b); x.l2 = (uint32_t)l2; x.o2 = (uint32_t)(s2 - b); x.o4 = (uint32_t)(s4 - b);
+        pos_ = (size_t)(n4 - map_) + (n4 < e ? 1 : 0);
+        return true;
+    }
+    int fd_ = -1;
+    const char* map_ = nullptr;
+    size_t size_ = 0, pos_ = 0;
+    bool fast_ = false;
+    SeqReader slow_;
+};
+
+// what next_read() does with a record, on the worker: same fields, same bytes
+void materialize(const RawRec& x, Read& r) {
+    if (!x.p) return;
+    const char* h = x.p + 1;
+    const size_t hl = x.l1 - 1;
+    size_t k = 0;
+    while (k < hl && !isspace((unsigned char)h[k])) k++;
+    r.qname.assign(h, k);
+    r.sequence.assign(x.p + x.o2, x.l2);
+    for (auto& c : r.sequence) c = (char)std::tolower((unsigned char)c);
+    r.qual.assign(x.p + x.o4, x.l2);
+    if (r.qname.length() > 2 && r.qname[r.qname.length() - 2] == '/') r.qname.erase(r.qname.length() - 2);
 }
 
 // persistent worker pool: every batch is split into contiguous slices, one per worker
@@ -297,6 +394,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
 
     struct Batch {
         std::vector<Read> a, b;               // b stays empty for single-end input; objects beyond n are spares of earlier batches
+        std::vector<RawRec> ra, rb;           // records the reader thread only split: the workers materialise them
         int n = 0;                            // reads (pairs) of this batch
         std::vector<std::string> text;        // rendered SAM, one chunk per worker slice, in input order
         std::vector<long> cnt;                // per slice: mapped1, printed1, mapped2, printed2
@@ -353,16 +451,17 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     };
 
     if (!o.unpairedQ.empty()) {
-        SeqReader rd;
+        ReadSource rd;
         if (!rd.open(o.unpairedQ.c_str())) { fprintf(stderr, "ERROR: file %s could not be read.", o.unpairedQ.c_str()); return 1; }
         stream(
             [&](Batch& B) {
                 int64_t cur = 0;
                 while (cur < bpCount && (size_t)B.n < readCap) {
-                    if ((int)B.a.size() <= B.n) B.a.emplace_back();
+                    if ((int)B.a.size() <= B.n) { B.a.emplace_back(); B.ra.emplace_back(); }
                     Read& r = B.a[B.n];
-                    if (!next_read(rd, r)) break;
-                    cur += (int64_t)r.sequence.length();
+                    const int got = rd.next(r, B.ra[B.n]);
+                    if (!got) break;
+                    cur += got == 1 ? (int64_t)B.ra[B.n].l2 : (int64_t)r.sequence.length();
                     B.n++;
                 }
                 return B.n > 0;
@@ -371,6 +470,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 Mapper& mp = *mappers[t];
                 std::string& txt = B.text[t];
                 long* c = &B.cnt[(size_t)t * 4];
+                for (int i = lo; i < hi; i++) materialize(B.ra[i], B.a[i]);
                 scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.map_unpaired(B.a[lo + i]); });
                 for (int i = lo; i < hi; i++) {
                     Read& r = B.a[i];
@@ -387,21 +487,26 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         printf("sequences read: %ld\nsequences mapped: %ld\nalignments printed: %ld\n", total, mapped1, printed1);
     }
     if (!o.pair1.empty() && !o.pair2.empty()) {
-        SeqReader r1, r2;
+        ReadSource r1, r2;
         if (!r1.open(o.pair1.c_str()) || !r2.open(o.pair2.c_str())) { fprintf(stderr, "ERROR: mate files could not be read."); return 1; }
         total = mapped1 = printed1 = mapped2 = printed2 = 0;
         stream(
             [&](Batch& B) {
                 int64_t cur = 0;
                 while (cur < bpCount && (size_t)B.n < readCap) {
-                    if ((int)B.a.size() <= B.n) { B.a.emplace_back(); B.b.emplace_back(); }
+                    if ((int)B.a.size() <= B.n) { B.a.emplace_back(); B.b.emplace_back(); B.ra.emplace_back(); B.rb.emplace_back(); }
                     Read& a = B.a[B.n];
                     Read& b = B.b[B.n];
-                    bool ok1 = next_read(r1, a);
-                    bool ok2 = next_read(r2, b);     // the reference keeps only the second status (src/main.cpp:157-158)
-                    (void)ok1;
+                    const int ok1 = r1.next(a, B.ra[B.n]);
+                    const int ok2 = r2.next(b, B.rb[B.n]);     // the reference keeps only the second status (src/main.cpp:157-158)
+                    if (!ok1) {
+                        // mate file 1 ended first: the reference's reader leaves its read object as it was.  The object may be a
+                        // spare of an earlier batch here, so give it the state a fresh read_t has
+                        B.ra[B.n].p = nullptr;
+                        a.qname.clear(); a.sequence.clear(); a.qual = "*";
+                    }
                     if (!ok2) break;
-                    cur += (int64_t)a.sequence.length();
+                    cur += ok1 == 1 ? (int64_t)B.ra[B.n].l2 : (int64_t)a.sequence.length();
                     B.n++;
                 }
                 return B.n > 0;
@@ -410,6 +515,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 Mapper& mp = *mappers[t];
                 std::string& txt = B.text[t];
                 long* c = &B.cnt[(size_t)t * 4];
+                for (int i = lo; i < hi; i++) { materialize(B.ra[i], B.a[i]); materialize(B.rb[i], B.b[i]); }
                 if (mp.splittable()) {
                     // the mates of a pair are independent until they are paired: twice the fibers, half the chain of batch rounds
                     scheds[t]->run(2 * (hi - lo), o.fibers, [&](int i) { mp.map_mate((i & 1) ? B.b[lo + (i >> 1)] : B.a[lo + (i >> 1)]); });

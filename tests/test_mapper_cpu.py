@@ -48,3 +48,51 @@ def test_host_mapper_c5_paired_long_reads():
     M.write_c5_paired(d)
     gold = json.load(open(os.path.join(G.GOLD, "c5_paired_md5.json")))
     assert M.md5(M.run_c5_paired(M.CPU_EXE, d, threads="8")) == gold["md5"]
+
+
+@pytest.mark.skipif(not os.path.exists(M.CPU_EXE), reason="tests/_cpu_mapper not built")
+def test_parallel_fastq_parse_equals_general_parser():
+    """the reader thread only splits plain 4-line FASTQ records (workers build the reads); anything else -- CRLF,
+    multi-line records, FASTA, gzip, a missing final newline, junk between records -- goes through the kseq restatement.
+    Same SAM either way, and the same as with the fast path switched off."""
+    import gzip
+    import subprocess
+    import golden_util as G
+    d = M.workdir()
+    recs = open(os.path.join(d, "454reads.fq")).read().rstrip("\n").split("\n")
+    recs = [recs[i:i + 4] for i in range(0, len(recs), 4)][:40]
+    variants = {
+        "plain": "".join("\n".join(r) + "\n" for r in recs),
+        "no_final_newline": "".join("\n".join(r) + "\n" for r in recs).rstrip("\n"),
+        "crlf_from_10": "".join(("\r\n" if i >= 10 else "\n").join(r) + ("\r\n" if i >= 10 else "\n") for i, r in enumerate(recs)),
+        "multiline_from_5": "".join((r[0] + "\n" + r[1][:50] + "\n" + r[1][50:] + "\n+\n" + r[3][:30] + "\n" + r[3][30:] + "\n") if i >= 5
+                                    else "\n".join(r) + "\n" for i, r in enumerate(recs)),
+        "names_with_comments": "".join("\n".join([r[0] + "/1 some comment\tx", r[1], "+" + r[0][1:], r[3]]) + "\n" for r in recs),
+        "junk_between": "".join("\n".join(r) + "\n\n" for r in recs),
+        "fasta": "".join(">" + r[0][1:] + "\n" + r[1] + "\n" for r in recs),
+    }
+    pre = os.path.join(d, "idx_pp")
+    subprocess.run([M.CPU_EXE, "index", "-r", "reference.fasta", "-p", pre, "-s", "12"], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+
+    def run(path, fast):
+        out = os.path.join(d, "pp.sam")
+        env = dict(os.environ)
+        if not fast:
+            env["ALFA_NO_FAST_FASTQ"] = "1"
+        p = subprocess.run([M.CPU_EXE, "align", "-i", pre, "-0", path, "-o", out, "-t", "3"], cwd=d, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-1000:]
+        return M.sam_body(out)
+    bodies = {}
+    for name, txt in variants.items():
+        path = os.path.join(d, "pp_%s.fq" % name)
+        open(path, "w", newline="").write(txt)
+        a, b = run(path, True), run(path, False)
+        assert a == b, name
+        assert a.count(b"\n") >= 40, name
+        bodies[name] = a
+    with gzip.open(os.path.join(d, "pp_plain.fq.gz"), "wt") as f:
+        f.write(variants["plain"])
+    assert run(os.path.join(d, "pp_plain.fq.gz"), True) == bodies["plain"]
+    assert bodies["no_final_newline"] == bodies["plain"] == bodies["junk_between"]
