@@ -1,11 +1,22 @@
 // alfalfa_main.cpp -- `alfalfa_amd`: the reference's `alfalfa index|align` commands on top of libalfa_hot (HIP only).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "mapper_cli.h"
+
+// ALFA_ALIAS_DEVICES=1 maps device ordinals beyond the visible ones back onto them (ordinal % count): `--gpus G` then runs G
+// worker groups, each with its own index copy and contexts, on fewer cards -- how the multi-GPU path is exercised on a one-GPU box
+static int physical(int device) {
+    static const bool alias = getenv("ALFA_ALIAS_DEVICES") != nullptr;
+    const int n = alfa_device_count();
+    return (alias && n > 0) ? device % n : device;
+}
 
 int main(int argc, char** argv) {
     alfa::HotBinding b;
     b.make_ops = [](int device, const alfa_host_index* hidx, alfa::HotOps* ops) {
+        device = physical(device);
         alfa_index* dix = nullptr;
         int rc = alfa_index_upload(alfa_host_index_view(hidx), device, &dix);
         if (rc) return rc;
@@ -22,7 +33,7 @@ int main(int argc, char** argv) {
         return 0;
     };
     b.release_ops = [](alfa::HotOps* ops) { alfa_index_free((alfa_index*)ops->index); };
-    b.bind_thread = [](int device) { (void)hipSetDevice(device); };
+    b.bind_thread = [](int device) { (void)hipSetDevice(physical(device)); };
     b.last_error = alfa_last_error;
     return alfa::mapper_main(argc, argv, b);
 }

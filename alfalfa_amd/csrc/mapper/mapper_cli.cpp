@@ -339,6 +339,8 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         return 1;
     }
     alfa_host_index* hidx = nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     if (o.command == "index") {
         if (alfa_host_index_build_fasta(o.ref_fasta.c_str(), o.K, o.hasSuflink, o.hasChild, o.hasKmer, &hidx)) {
             fprintf(stderr, "ERROR: %s\n", alfa_last_error());
@@ -358,6 +360,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         }
         if (o.saveIndex) alfa_host_index_save(hidx, o.index_prefix.c_str());
     }
+    const double t_index_ready = since_start();
     RefIndex idx;
     idx.h = hidx;
     idx.v = alfa_host_index_view(hidx);
@@ -374,6 +377,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     for (int g = 0; g < G; ++g)
         if (bind.make_ops(o.device + g, hidx, &ops[g])) { fprintf(stderr, "ERROR: cannot set up the hot path on device %d: %s\n", o.device + g, bind.last_error()); return 1; }
 
+    const double t_device_ready = since_start();
     FILE* out = fopen(o.outputName.c_str(), "w");
     if (!out) { fprintf(stderr, "ERROR: cannot write %s\n", o.outputName.c_str()); return 1; }
     fputs(sam_header(idx, argc, argv).c_str(), out);
@@ -386,6 +390,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         if (const char* lp = getenv("ALFA_TASK_LOG")) scheds[t]->set_task_log(std::string(lp) + "." + std::to_string(t));
         mappers[t].reset(new Mapper(idx, o.aln, o.paired, *scheds[t]));
     });
+    const double t_pool_ready = since_start();
     // Batches follow the reference's driver (BUFFER_SIZE bases per thread, src/main.cpp:54,116) but are also capped at one
     // wave of fibers per worker so that parsing (reader thread), mapping + SAM rendering (worker pool) and writing
     // (writer thread) of successive batches overlap.  Batch boundaries do not influence the output.
@@ -402,6 +407,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     typedef std::unique_ptr<Batch> BatchP;
     long total = 0, mapped1 = 0, mapped2 = 0, printed1 = 0, printed2 = 0;
     double t_parse = 0, t_map = 0, t_print = 0;
+    std::vector<double> w_build((size_t)T, 0.0), w_run((size_t)T, 0.0), w_render((size_t)T, 0.0);   // per worker, --stats
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
     // fill(batch) -> false at end of input; work(batch, t, lo, hi) maps and renders reads [lo,hi) on worker t
@@ -470,8 +476,13 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 Mapper& mp = *mappers[t];
                 std::string& txt = B.text[t];
                 long* c = &B.cnt[(size_t)t * 4];
+                const double tb0 = now();
                 for (int i = lo; i < hi; i++) materialize(B.ra[i], B.a[i]);
+                const double tb1 = now();
                 scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.map_unpaired(B.a[lo + i]); });
+                const double tb2 = now();
+                w_build[t] += tb1 - tb0; w_run[t] += tb2 - tb1;
+                struct Fin { double& acc; double t0; decltype(now)& clk; ~Fin() { acc += clk() - t0; } } fin{w_render[t], tb2, now};
                 for (int i = lo; i < hi; i++) {
                     Read& r = B.a[i];
                     if (r.alignments.empty()) txt += r.emptyAlignment(false, false, true);
@@ -560,6 +571,11 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
             s.glob_tasks += x.glob_tasks; s.align_calls += x.align_calls; s.align_tasks += x.align_tasks; s.hot_seconds += x.hot_seconds;
         }
         fprintf(stderr, "#PHASES parse %.3f map %.3f print %.3f\n", t_parse, t_map, t_print);
+        fprintf(stderr, "#STARTUP index_loaded %.3f device_ready %.3f workers_ready %.3f done %.3f (seconds since start)\n", t_index_ready,
+                t_device_ready, t_pool_ready, since_start());
+        double sb = 0, sr = 0, sn = 0, mr = 0;
+        for (int t = 0; t < T; ++t) { sb += w_build[t]; sr += w_run[t]; sn += w_render[t]; mr = std::max(mr, w_run[t]); }
+        fprintf(stderr, "#WORKERS threads %d build_reads %.3f map %.3f (slowest %.3f) render %.3f (thread-seconds)\n", T, sb, sr, mr, sn);
         fprintf(stderr, "#STATS rounds %ld seed_calls %ld seed_queries %ld extend %ld/%ld nw %ld/%ld global %ld/%ld align %ld/%ld hot_seconds %.3f\n",
                 (long)s.rounds, (long)s.seed_calls, (long)s.seed_queries, (long)s.ext_calls, (long)s.ext_tasks, (long)s.nw_calls,
                 (long)s.nw_tasks, (long)s.glob_calls, (long)s.glob_tasks, (long)s.align_calls, (long)s.align_tasks, s.hot_seconds);

@@ -68,3 +68,15 @@ def test_gpu_mapper_vs_oracle_mapper_synthetic(gpu):
             outs.append(M.sam_body(out))
         assert outs[0] == outs[1], tag
         assert outs[0].count(b"\n") > 100
+
+
+def test_gpu_mapper_two_device_contexts(gpu):
+    """`--gpus 2` on this one-GPU box with ALFA_ALIAS_DEVICES: two worker groups, two resident index copies, two sets of HIP
+    contexts; output identical to the reference's and independent of the grouping"""
+    os.environ["ALFA_ALIAS_DEVICES"] = "1"
+    try:
+        for name in ("454_s12", "pe_s12_rescue"):
+            body = M.run_config(M.GPU_EXE, name, ["-t", "4", "--gpus", "2"])
+            assert M.md5(body) == M.golden_md5(name), name
+    finally:
+        del os.environ["ALFA_ALIAS_DEVICES"]

@@ -96,3 +96,14 @@ def test_parallel_fastq_parse_equals_general_parser():
         f.write(variants["plain"])
     assert run(os.path.join(d, "pp_plain.fq.gz"), True) == bodies["plain"]
     assert bodies["no_final_newline"] == bodies["plain"] == bodies["junk_between"]
+
+
+@pytest.mark.skipif(not os.path.exists(M.CPU_EXE), reason="tests/_cpu_mapper not built")
+@pytest.mark.parametrize("name", ["454_s12", "pe_s12", "pe_s12_rescue"])
+def test_multi_gpu_worker_groups_keep_output_and_order(name):
+    """`--gpus G` binds worker thread t to hot-path context t mod G (one index copy per context), batches are split
+    over all workers and written in input order.  With G = 2 and 3 logical contexts (oracle-bound here) the SAM must be the
+    reference's, byte for byte, whatever the thread count."""
+    gold = M.golden_body(name)
+    for gpus, threads in ((2, "4"), (3, "5"), (2, "2")):
+        assert M.run_config(M.CPU_EXE, name, ["-t", threads, "--gpus", str(gpus)]) == gold, (gpus, threads)

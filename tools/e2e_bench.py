@@ -90,7 +90,7 @@ def main():
         t0 = time.time()
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         dt = time.time() - t0
-        stats = [l for l in p.stderr.decode().split("\n") if l.startswith("#STATS") or l.startswith("#PHASES")]
+        stats = [l for l in p.stderr.decode().split("\n") if l.startswith(("#STATS", "#PHASES", "#WORKERS", "#STARTUP"))]
         import hashlib
         body = b"\n".join(l for l in open(out, "rb").read().split(b"\n") if not l.startswith(b"@PG"))
         md5s[name] = hashlib.md5(body).hexdigest()
