@@ -23,7 +23,13 @@
 
 #include "../../include/alfa_index.h"
 #include "errors.h"
+#include "host_index_hook.h"
 #include "seqio.h"
+
+namespace alfa {
+int (*g_device_construct)(int device, DeviceBuildIO* io) = nullptr;
+int g_build_device = -1;
+}  // namespace alfa
 
 struct alfa_host_index {
     std::vector<std::string> descr;
@@ -130,7 +136,7 @@ uint32_t bitadd(unsigned char c) {
     }
 }
 
-void construct(alfa_host_index& ix) {
+int construct(alfa_host_index& ix) {
     const int64_t K = ix.K;
     // ---- init(): pad with '$' to a multiple of K, then K more (src/sparseSA.cpp:108-122)
     std::string& S = ix.S;
@@ -140,6 +146,27 @@ void construct(alfa_host_index& ix) {
     const int64_t N = ix.N, n = N / K;
     ix.logN = (int64_t)std::ceil(std::log((double)(N / K)) / std::log(2.0));
     ix.NKm1 = n - 1;
+
+    // ---- the same arrays from the GPU builder (index_build.hip) when alfa_index_build_on_device() has switched it on.
+    // (K = 1 relies on the final '$' being the smallest suffix, which a text with bytes below '$' would break: host then.)
+    if (alfa::g_device_construct && (K > 1 || std::none_of(S.begin(), S.end(), [](char c) { return (unsigned char)c < (unsigned char)'$'; }))) {
+        ix.SA.assign((size_t)n, 0); ix.LCP.assign((size_t)n, 0);
+        if (ix.hasChild) ix.CHILD.assign((size_t)n, -1);
+        if (ix.hasKmer) ix.KMR.assign(2 * (size_t)TABLE, 0);
+        if (ix.hasSufLink) ix.ISA.assign((size_t)n, 0);
+        S.append(16, '\0');
+        alfa::DeviceBuildIO io;
+        io.S = (const uint8_t*)S.data(); io.N = N; io.K = K;
+        io.SA = ix.SA.data(); io.LCP = ix.LCP.data();
+        io.CHILD = ix.hasChild ? ix.CHILD.data() : nullptr;
+        io.KMR = ix.hasKmer ? ix.KMR.data() : nullptr;
+        io.ISA = ix.hasSufLink ? ix.ISA.data() : nullptr;
+        io.Midx = &ix.Midx; io.Mval = &ix.Mval;
+        const int rc = alfa::g_device_construct(alfa::g_build_device, &io);
+        if (rc) return rc;
+        ix.refresh_view();
+        return ALFA_OK;
+    }
 
     // ---- suffix array
     std::vector<int32_t> sa32;
@@ -258,13 +285,15 @@ void construct(alfa_host_index& ix) {
     }
     S.append(16, '\0');  // read slack for the un-guarded S[SA+depth] probes
     ix.refresh_view();
+    return ALFA_OK;
 }
 
 int finish_build(alfa_host_index* ix, int64_t K, int suflink, int child, int kmer, alfa_host_index** out) {
     if (K < 1) { delete ix; return alfa::fail(ALFA_EINVAL, "index sparseness K must be >= 1"); }
     ix->K = K; ix->hasSufLink = suflink != 0; ix->hasChild = child != 0; ix->hasKmer = kmer != 0;
     if ((int64_t)ix->S.size() / K > 0x7fffff00LL) { delete ix; return alfa::fail(ALFA_EINVAL, "N/K exceeds the int32 range of the index arrays"); }
-    construct(*ix);
+    const int rc = construct(*ix);
+    if (rc) { delete ix; return rc; }
     *out = ix;
     return ALFA_OK;
 }

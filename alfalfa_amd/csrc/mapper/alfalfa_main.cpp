@@ -35,5 +35,6 @@ int main(int argc, char** argv) {
     b.release_ops = [](alfa::HotOps* ops) { alfa_index_free((alfa_index*)ops->index); };
     b.bind_thread = [](int device) { (void)hipSetDevice(physical(device)); };
     b.last_error = alfa_last_error;
+    b.index_build_on_device = [](int device) { return alfa_index_build_on_device(physical(device)); };
     return alfa::mapper_main(argc, argv, b);
 }

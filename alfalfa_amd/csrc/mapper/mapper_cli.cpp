@@ -35,6 +35,7 @@ struct Options {
     // extensions of this implementation
     int fibers = 4096, gpus = 1, device = 0;
     bool stats = false;
+    bool gpuIndex = false;      // --gpu-index: build the index arrays on the GPU (index_build.hip)
 };
 
 int seed_type(const std::string& t) {       // parseSeedType src/options.cpp:155-172 (CLI names are shifted)
@@ -112,6 +113,7 @@ bool parse(int argc, char** argv, Options& o) {
         else if (is(nullptr, "gpus")) o.gpus = atoi(need(i));
         else if (is(nullptr, "device")) o.device = atoi(need(i));
         else if (is(nullptr, "stats")) o.stats = true;
+        else if (is(nullptr, "gpu-index")) o.gpuIndex = true;
         else { fprintf(stderr, "ERROR: unknown option %s\n", a.c_str()); exit(1); }
     }
     if (o.command == "index") {
@@ -333,7 +335,7 @@ class Chan {
 int mapper_main(int argc, char** argv, const HotBinding& bind) {
     Options o;
     if (!parse(argc, argv, o)) {
-        fprintf(stderr, "usage: %s index -r ref.fa [-s K] [-p prefix] [--no-child] [--suflink] [--no-kmer]\n"
+        fprintf(stderr, "usage: %s index -r ref.fa [-s K] [-p prefix] [--no-child] [--suflink] [--no-kmer] [--gpu-index [--device D]]\n"
                         "       %s align (-r ref.fa | -i index) (-0 reads.fq | -1 m1.fq -2 m2.fq) [-o out.sam] [reference options]\n",
                 argv[0], argv[0]);
         return 1;
@@ -341,6 +343,10 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     alfa_host_index* hidx = nullptr;
     const auto t_start = std::chrono::steady_clock::now();
     auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+    if (o.gpuIndex) {
+        if (!bind.index_build_on_device) { fprintf(stderr, "ERROR: --gpu-index: this build has no GPU index builder\n"); return 1; }
+        if (bind.index_build_on_device(o.device)) { fprintf(stderr, "ERROR: %s\n", bind.last_error()); return 1; }
+    }
     if (o.command == "index") {
         if (alfa_host_index_build_fasta(o.ref_fasta.c_str(), o.K, o.hasSuflink, o.hasChild, o.hasKmer, &hidx)) {
             fprintf(stderr, "ERROR: %s\n", alfa_last_error());

@@ -15,6 +15,8 @@ struct HotBinding {
     std::function<void(HotOps* ops)> release_ops;
     std::function<void(int device)> bind_thread;     // called once in every worker thread
     std::function<const char*()> last_error;
+    // optional: build the index arrays on `device` from now on (--gpu-index); unset in bindings without a GPU builder
+    std::function<int(int device)> index_build_on_device;
 };
 
 int mapper_main(int argc, char** argv, const HotBinding& bind);

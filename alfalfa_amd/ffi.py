@@ -203,6 +203,11 @@ class HostIndex:
             pass
 
 
+def index_build_on_device(device):
+    """device >= 0: HostIndex.build_* construct their arrays on that GPU; -1: on the host again"""
+    check(lib().alfa_index_build_on_device(int(device)))
+
+
 def make_seed_queries(reads, min_len, max_count, sparse_q, max_smem_cont=0):
     """reads: list of bytes; scalar or per-read parameter lists."""
     n = len(reads)

@@ -37,6 +37,12 @@ int alfa_host_index_load(const char* prefix, alfa_host_index** out);
 /* sparseSA::save: byte-identical files */
 int alfa_host_index_save(const alfa_host_index*, const char* prefix);
 
+/* Index construction on the GPU (libalfa_hot only; replaces sparseSA::construct / computeLCP / computeChild / computeKmer,
+ * src/sparseSA.cpp:478-558, 161-313, with data-parallel kernels): after alfa_index_build_on_device(device >= 0) the two build
+ * calls above compute SA, LCP (+ overflow table), CHILD, KMR and ISA on that device -- the same arrays, bit for bit -- and
+ * keep doing so until alfa_index_build_on_device(-1).  Process-wide switch; not meant to be flipped while builds run. */
+int alfa_index_build_on_device(int device);
+
 const alfa_index_view* alfa_host_index_view(const alfa_host_index*);
 const char* alfa_host_index_descr(const alfa_host_index*, int seq);
 /* sparseSA::from_set (src/sparseSA.h:173-180) */
