@@ -610,7 +610,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_note": "raw FETCH_SIZE x 1024 per dispatch (profiles/r01_pmc_traffic.json). Calibrated on this access pattern "
+            "traffic_note": "raw FETCH_SIZE x 1024 per dispatch (profiles/*_pmc_traffic.json, the latest round). Calibrated on this access pattern "
                             "(tools/fetch_calib.hip, profiles/r01_fetch_calibration.csv): an isolated 4/8/16-byte gather from a 2 GiB "
                             "table tallies 64 B, a wide streaming read tallies half its bytes (the guide's x2 case); the seed "
                             "kernels issue gathers, so the raw figure is used",
