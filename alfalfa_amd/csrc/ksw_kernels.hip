@@ -41,7 +41,6 @@ namespace {
 
 constexpr int NEG_INF = -0x40000000;  // MINUS_INF, ksw.c:454
 constexpr int WPB = 4;                // wavefronts (tasks) per workgroup
-constexpr int BAIL_HDR = 64;          // words in front of a give-up list (word 0 = count): the list is zeroed by a 256-byte memset
 enum { MODE_NW = 0, MODE_GLOBAL = 1, MODE_EXTEND = 2 };
 
 struct DevTask {
@@ -105,15 +104,11 @@ __device__ __forceinline__ int score_of(uint64_t mr, uint32_t q) { return (int)(
 __device__ __forceinline__ int score_at(uint64_t mr, uint32_t q8) { return (int)(int8_t)(mr >> q8); }
 
 // ---------------------------------------------------------------- wave-per-task kernel
+// one task on the 64 lanes of the calling wavefront (bands of up to 64 x C diagonals); all lanes call it together
 template <int MODE, int C>
-__global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __restrict__ tasks, int ntask,
-                                                           const uint8_t* __restrict__ seq,
-                                                           const DevParams* __restrict__ prm,
-                                                           int32_t* __restrict__ out, uint8_t* __restrict__ zbuf) {
-    const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
-    if (wave >= ntask) return;
+__device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __restrict__ seq, const DevParams* __restrict__ prm,
+                                          int32_t* __restrict__ out, uint8_t* __restrict__ zbuf) {
     const int lane = lane_id();
-    const DevTask T = tasks[wave];
     const uint8_t* __restrict__ q = seq + T.qoff;
     const uint8_t* __restrict__ tg = seq + T.toff;
     const int qlen = T.qlen, tlen = T.tlen, w = T.w;
@@ -151,15 +146,35 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
 
     int beg = 0, end = qlen;                                    // EXTEND state
     int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
-    int tnext = tg[0];
+    // the row's target residue and the query residue that enters the top diagonal come out of 8-byte windows that are loaded
+    // eight rows ahead, and the matrix rows sit in registers: no row waits for a memory round trip
+    uint64_t mrow[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mrow[k] = prm->matrow[k];
+    auto load8 = [](const uint8_t* __restrict__ p, int from, int len) -> uint64_t {      // bytes from..from+7 of p[0..len), 0 outside
+        uint64_t v = 0;
+        if (from >= 0 && from + 8 <= len) __builtin_memcpy(&v, p + from, 8);
+        else
+            for (int k = 0; k < 8; ++k)
+                if (from + k >= 0 && from + k < len) v |= (uint64_t)p[from + k] << (8 * k);
+        return v;
+    };
+    const int xq0 = 1 - w + ROWB - 1;                           // query position fed in after row 0
+    uint64_t tcur = load8(tg, 0, tlen), tnxt = load8(tg, 8, tlen);
+    uint64_t qcur = load8(q, xq0, qlen), qnxt = load8(q, xq0 + 8, qlen);
 
     for (int i = 0; i < tlen; ++i) {
-        const int tch = __builtin_amdgcn_readfirstlane(tnext);
-        if (i + 1 < tlen) tnext = tg[i + 1];
-        const uint64_t mr = prm->matrow[tch];
-        // new query character entering the top diagonal on the next row
-        const int xq = i + 1 - w + ROWB - 1;
-        const uint32_t qfeed = (xq >= 0 && xq < qlen) ? 8u * q[xq] : 0u;
+        const int ph = 8 * (i & 7);
+        const int tch = __builtin_amdgcn_readfirstlane((int)((tcur >> ph) & 0xffu));
+        const int xq = i + xq0;
+        const uint32_t qfeed = (xq >= 0 && xq < qlen) ? 8u * (uint32_t)((qcur >> ph) & 0xffu) : 0u;
+        if ((i & 7) == 7) {
+            tcur = tnxt; tnxt = load8(tg, i + 9, tlen);
+            qcur = qnxt; qnxt = load8(q, xq + 9, qlen);
+        }
+        uint64_t mr = mrow[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) mr = tch == k ? mrow[k] : mr;
 
         if (MODE == MODE_EXTEND) {
             if (beg < i - w) beg = i - w;
@@ -329,6 +344,16 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
     }
 }
 
+template <int MODE, int C>
+__global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __restrict__ tasks, int ntask,
+                                                           const uint8_t* __restrict__ seq,
+                                                           const DevParams* __restrict__ prm,
+                                                           int32_t* __restrict__ out, uint8_t* __restrict__ zbuf) {
+    const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (wave >= ntask) return;
+    wave_task<MODE, C>(tasks[wave], seq, prm, out, zbuf);
+}
+
 // ---------------------------------------------------------------- group kernel: 16 lanes per task, 4 tasks per wavefront
 // Short-read tasks have bands of 10-60 diagonals and 20-50 columns: one task per 64-lane wave leaves most lanes idle and
 // the kernel is bound by the instructions issued per row.  Here a DPP row (16 lanes) owns a task -- same band-diagonal
@@ -404,23 +429,15 @@ template <int MODE, int C, int GL>
 __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __restrict__ tasks, int ntask,
                                                             const uint8_t* __restrict__ seq,
                                                             const DevParams* __restrict__ prm,
-                                                            int32_t* __restrict__ out, uint8_t* __restrict__ zbuf,
-                                                            const int* __restrict__ ilist) {
-    // ilist != nullptr: run tasks[ilist[BAIL_HDR + k]] for k < ilist[0] (the tasks ksw_lane2_kernel gave up on); ntask bounds the grid
+                                                            int32_t* __restrict__ out, uint8_t* __restrict__ zbuf) {
     __shared__ uint64_t s_mat[8];
-    if (ilist) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) ((int*)ilist)[BAIL_HDR + ntask] = ilist[0];      // kept for alfa_dp_batch_giveups
-        ntask = ilist[0] < ntask ? ilist[0] : ntask;
-        if ((int)(blockIdx.x * WPB * (64 / GL)) >= ntask) return;
-    }
     if (threadIdx.x < 8) s_mat[threadIdx.x] = prm->matrow[threadIdx.x];
     __syncthreads();
     const int lane = lane_id();
     const int gl = lane & (GL - 1);
     const int task = (blockIdx.x * WPB + (threadIdx.x >> 6)) * (64 / GL) + lane / GL;
     const bool valid = task < ntask;
-    const int tsel = valid ? task : ntask - 1;
-    const DevTask T = tasks[ilist ? ilist[BAIL_HDR + tsel] : tsel];
+    const DevTask T = tasks[valid ? task : ntask - 1];
     const uint8_t* __restrict__ q = seq + T.qoff;
     const uint8_t* __restrict__ tg = seq + T.toff;
     const int qlen = T.qlen, tlen = valid ? T.tlen : 0, w = T.w;
@@ -623,9 +640,8 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
         tnext = tnext2;
     }
 
-    if (!valid) return;
     if (MODE == MODE_EXTEND) {
-        if (gl == 0) {
+        if (valid && gl == 0) {
             ExtOut* o = (ExtOut*)out + T.orig;
             o->score = mx; o->qle = max_j + 1; o->tle = max_i + 1; o->gtle = max_ie + 1; o->gscore = gscore; o->max_off = max_off;
         }
@@ -635,7 +651,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
 #pragma unroll
         for (int c = 0; c < C; ++c) hv = (gl * C + c == dl) ? Hd[c] : hv;
         const int score = (dl >= 0 && dl <= 2 * w) ? grp_max<GL>(hv) : NEG_INF;
-        if (gl == 0) out[T.orig] = score;
+        if (valid && gl == 0) out[T.orig] = score;
     }
 }
 
@@ -971,6 +987,7 @@ __global__ __launch_bounds__(64) void ksw_lane_kernel(const DevTask* __restrict_
 // The row loop must stay ONE basic block (no break, no short-circuit &&): any control flow in it makes the register
 // allocator double-buffer the band.
 constexpr int QPAD = 7;               // query code of positions outside the query: needs m <= 7
+constexpr int DEAD = -(1 << 28);      // ksw_extend: H of a dead (zero) boundary cell as the diagonal predecessor
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }           // v_max3_i32
 // lane i <- lane i-1 / i+1 inside its DPP row of 16 (groups of G lanes never straddle a row); callers mask the group edges
@@ -1008,14 +1025,8 @@ __device__ __forceinline__ void lane2_body(const DevTask* __restrict__ tasks, in
     const int zdrop = prm->zdrop;
     int h0 = T.h0;
     if (MODE == MODE_EXTEND && h0 < 0) h0 = 0;
-    // ksw_extend: from the first row iz whose first-column value max(h0 - gapo - gape*(i+1), 0) is 0 the reference moves `beg`
-    // up by one per row (ksw.c:435-436 stops at eh[beg].h == 0): the band keeps min(w, iz) diagonals on its left from there on
-    int iz = 0x3fffffff;
-    if (MODE == MODE_EXTEND) {
-        if (h0 <= gapo) iz = 0;
-        else if (gape > 0) iz = (h0 - gapo + gape - 1) / gape - 1;
-        iz = iz < 0 ? 0 : iz;
-    }
+    // (ksw_extend tasks whose first-column value max(h0 - gapo - gape*(i+1), 0) reaches 0 while the band still touches column 0
+    // never come here -- lane2_class: the reference may then move `beg` depending on E at the band's edge, ksw.c:435-436)
     const int tmax = wave_max(tlen);
     const int qmax = wave_max(valid ? qlen : 0);
 
@@ -1025,30 +1036,37 @@ __device__ __forceinline__ void lane2_body(const DevTask* __restrict__ tasks, in
     for (int d = g; d < TW; d += G) tring[d * TPW + tw] = 0u;
     __syncthreads();
     {
-        uint8_t* rb = (uint8_t*)ring;
-        uint8_t* tb = (uint8_t*)tring;
-        const int lim = RW * 4;
-        // four independent byte loads in flight per lane and trip (one load per trip is one memory round trip per byte)
-        for (int j0 = 4 * g; j0 < qmax; j0 += 4 * G) {
-            uint8_t v[4];
+        // One (unaligned) dword load per four residues, four loads in flight per lane: the load addresses are chosen so that
+        // every loaded dword lands on a whole dword of the string -- dword k of the query stream starts at residue 4k - sq,
+        // sq = w & 3; the host packs sequences from byte 16 of the buffer on and leaves slack behind them, so the up to three
+        // bytes read in front of / behind a sequence exist (they are masked to PAD / 0).  This is what a cold batch waits for.
+        const uint32_t PAD4 = 0x01010101u * QPAD;
+        auto stage = [&](const uint8_t* __restrict__ src, int len, int shift, int dword0, uint32_t pad4, uint32_t* __restrict__ dst, int ndw, int cap) {
+            const int nmax = wave_max(ndw);
+            for (int k0 = g; k0 < nmax; k0 += 4 * G) {
+                uint32_t x[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = (valid && j0 + u < qlen) ? q[j0 + u] : (uint8_t)QPAD;
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u * G;
+                    x[u] = 0;
+                    if (k < ndw) __builtin_memcpy(&x[u], src + 4 * k - shift, 4);
+                }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int p = j0 + u + w;
-                if (valid && j0 + u < qlen && p < lim) rb[((p >> 2) * TPW + tw) * 4 + (p & 3)] = v[u];
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u * G;
+                    const int jf = 4 * k - shift;                                   // residue of the dword's first byte
+                    int nlo = -jf, nhi = jf + 4 - len;
+                    nlo = nlo < 0 ? 0 : nlo;
+                    nhi = nhi < 0 ? 0 : (nhi > 4 ? 4 : nhi);
+                    const uint32_t mask = (uint32_t)(0xffffffffull << (8 * nlo)) & (uint32_t)(0xffffffffull >> (8 * nhi));
+                    if (k < ndw && k + dword0 < cap) dst[(k + dword0) * TPW + tw] = (x[u] & mask) | (pad4 & ~mask);
+                }
             }
-        }
-        for (int j0 = 4 * g; j0 < tmax; j0 += 4 * G) {
-            uint8_t v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = (j0 + u < tlen) ? tg[j0 + u] : (uint8_t)0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int p = j0 + u + G;
-                if (j0 + u < tlen) tb[((p >> 2) * TPW + tw) * 4 + (p & 3)] = v[u];
-            }
-        }
+        };
+        const int sq = w & 3;
+        stage(q, qlen, sq, (w - sq) >> 2, PAD4, ring, valid ? (qlen + sq + 3) >> 2 : 0, RW);
+        constexpr int ST = G & 3;
+        stage(tg, tlen, ST, (G - ST) >> 2, 0u, tring, (tlen + ST + 3) >> 2, TW);
     }
     __syncthreads();
 
@@ -1064,7 +1082,10 @@ __device__ __forceinline__ void lane2_body(const DevTask* __restrict__ tasks, in
             const int a = eh1 - (j0 - 1) * gape;                          // ksw.c:377-379
             const int bq = h0 - (gapo + gape * (w - s));                  // H(w-s-1, -1), ksw.c:395-396
             v = j0 == 0 ? h0 : (j0 > 0 ? a : bq);
-            v = v > 0 ? v : 0;
+            // a zero in row -1 / column -1 is a dead cell: the reference extends no diagonal out of it (M ? M + s : 0,
+            // ksw.c:403).  DEAD makes the first cell of such a diagonal max(e, f) as there; if that is 0 the task gives up
+            // like on any other in-band zero
+            v = v > 0 ? v : DEAD;
             E[c] = 0;
         } else {
             const int a = (j0 <= w && j0 <= qlen) ? -(gapo + gape * j0) : NEG_INF;   // ksw.c:486-489 / 558-561
@@ -1112,8 +1133,7 @@ __device__ __forceinline__ void lane2_body(const DevTask* __restrict__ tasks, in
         const uint32_t ph = (uint32_t)pos & 3u;
         const int rdir = rowv ? r : tcap;              // ksw_global: rows outside the task write to a spare row of the direction bits
         // band of this row in diagonal coordinates: slot s is inside iff db <= s < de
-        const int rz = (MODE == MODE_EXTEND && r > iz) ? iz : r;
-        const int db = w - rz > 0 ? w - rz : 0;
+        const int db = w - r > 0 ? w - r : 0;
         int de = qlen - r + w;
         de = de < 2 * w + 1 ? de : 2 * w + 1;
         const bool nonempty = de > db;
@@ -1188,7 +1208,7 @@ __device__ __forceinline__ void lane2_body(const DevTask* __restrict__ tasks, in
             zlast = zmin;
             // row epilogue of ksw_extend (ksw.c:424-433), branch-free; only the task's last lane has the whole row
             const bool live = rowv & !done;
-            const int beg = r - w + db;                      // = max(r - w, 0) before row iz
+            const int beg = r - w + db;                      // = max(r - w, 0)
             int end = r + w + 1;
             end = end < qlen ? end : qlen;
             int h1i = h0 - (gapo + gape * (r + 1));
@@ -1234,17 +1254,24 @@ __device__ __forceinline__ void lane2_body(const DevTask* __restrict__ tasks, in
         }
 #pragma unroll
         for (int o = 1; o < G; o <<= 1) gk = max(gk, __shfl_xor(gk, o, 64));
-        if (!valid || g != G - 1) return;
-        if (give_up) {
-            const int slot = atomicAdd(bail, 1);
-            bail[BAIL_HDR + slot] = task_base + tpos;
-            return;
+        const bool mine = valid && g == G - 1;
+        if (mine && !give_up) {
+            int gscore = -1, max_ie = -1;
+            if (gk >= 0) { gscore = gk >> 6; max_ie = qlen - 1 + w - (63 - (gk & 63)); }
+            if (quirk_i >= 0 && !(gscore > quirk_h1)) { gscore = quirk_h1; max_ie = quirk_i; }
+            ExtOut* o = (ExtOut*)out + T.orig;
+            o->score = mx; o->qle = max_j + 1; o->tle = max_i + 1; o->gtle = max_ie + 1; o->gscore = gscore; o->max_off = max_off;
         }
-        int gscore = -1, max_ie = -1;
-        if (gk >= 0) { gscore = gk >> 6; max_ie = qlen - 1 + w - (63 - (gk & 63)); }
-        if (quirk_i >= 0 && !(gscore > quirk_h1)) { gscore = quirk_h1; max_ie = quirk_i; }
-        ExtOut* o = (ExtOut*)out + T.orig;
-        o->score = mx; o->qle = max_j + 1; o->tle = max_i + 1; o->gtle = max_ie + 1; o->gscore = gscore; o->max_off = max_off;
+        // tasks that gave up (rare: about one in 10^5 on the C3 stream) run here and now, one at a time on all 64 lanes of this
+        // wavefront, with the kernel that follows the reference's moving band (ksw_wave_kernel's body): no list, no second launch
+        uint64_t todo = __ballot(mine && give_up);
+        if (todo && lane == 0) atomicAdd(bail, (int)__popcll(todo));
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int tp = __shfl(tpos, src, 64);
+            wave_task<MODE_EXTEND, 1>(tasks[tp], seq, prm, out, nullptr);
+        }
         return;
     }
     // NW / GLOBAL: eh[qlen].h = H(tlen-1, qlen-1), frozen in diagonal qlen - tlen + w
@@ -1289,8 +1316,9 @@ __device__ __forceinline__ void lane2_body(const DevTask* __restrict__ tasks, in
 
 // One launch per ksw kind: the grid is the concatenation of the classes' blocks (the box gives a process 4 hardware queues:
 // a launch per class and chunk would serialise on them), long-target classes first.
-constexpr int NL2 = 6;
-struct L2Grid { int blk_end[NL2]; int task_start[NL2]; int task_cnt[NL2]; int tcap[NL2]; };
+constexpr int NL2 = 11;
+// grid position k (longest critical path first) holds class cls[k]
+struct L2Grid { int blk_end[NL2]; int task_start[NL2]; int task_cnt[NL2]; int tcap[NL2]; int cls[NL2]; };
 template <int MODE>
 __global__ __launch_bounds__(64) void ksw_lane2_kernel(L2Grid L, const DevTask* __restrict__ tasks, const uint8_t* __restrict__ seq,
                                                       const DevParams* __restrict__ prm, int32_t* __restrict__ out,
@@ -1301,23 +1329,28 @@ __global__ __launch_bounds__(64) void ksw_lane2_kernel(L2Grid L, const DevTask* 
     const int blk = b - (k ? L.blk_end[k - 1] : 0);
     const DevTask* t = tasks + L.task_start[k];
     const int n = L.task_cnt[k], base = L.task_start[k], tcap = L.tcap[k];
-    // the classes with the long targets are the launch's critical path: their wavefronts issue ahead of the others on a SIMD
+    // the classes at the front of the grid are the launch's critical path: their wavefronts issue ahead of the others on a SIMD
     if (k == 0) __builtin_amdgcn_s_setprio(3);
     else if (k <= 2) __builtin_amdgcn_s_setprio(2);
-    switch (k) {
+    switch (L.cls[k]) {
     case 0: lane2_body<MODE, 64, 16>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
     case 1: lane2_body<MODE, 32, 8>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
     case 2: lane2_body<MODE, 16, 4>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
     case 3: lane2_body<MODE, 48, 4>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
     case 4: lane2_body<MODE, 32, 2>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
-    default: lane2_body<MODE, 16, 1>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
+    case 5: lane2_body<MODE, 16, 1>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
+    case 6: lane2_body<MODE, 8, 1>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
+    case 7: lane2_body<MODE, 12, 1>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
+    case 8: lane2_body<MODE, 40, 2>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
+    case 9: lane2_body<MODE, 48, 2>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
+    default: lane2_body<MODE, 24, 1>(t, n, seq, prm, out, cig, ncig, bail, base, tcap, blk); break;
     }
 }
 
 }  // namespace
 
 // ================================================================= host side
-constexpr int NBIN = 16;
+constexpr int NBIN = 9 + NL2 + 1;
 constexpr int L2BIN = 9;        // first lane2 bin (NL2 classes, then ksw_global's long targets: class 0 in a launch of its own)
 constexpr int L2_TCAP = 512;    // longest target (rows) of the band-in-registers kernel
 struct alfa_dp_batch {
@@ -1335,6 +1368,7 @@ struct alfa_dp_batch {
     int64_t cig_words = 0, cells = 0, zbytes = 0, eh_items = 0;
     size_t seq_bytes = 0, out_bytes = 0;
     alfa::DevBuf d_seq, d_tasks, d_out, d_z, d_cig, d_eh, d_bail;
+    int launches = 0;                 // d_bail[0] counts the give-ups of all launches so far
     alfa::PinBuf h_out, h_cig;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool launched = false;
@@ -1383,22 +1417,30 @@ int64_t band_cells(int64_t qlen, int64_t tlen, int64_t w) {
     return c;
 }
 
-// ksw_lane2_kernel's classes, in grid order (long targets first): ND band diagonals over G lanes.  A band width has a
-// narrow form for short targets (few lanes per task: least work per cell) and a wide form for long ones (the task's
-// critical path is (rows + G - 1) x ND/G slots).  max_rows[0] bounds ksw_nw / ksw_extend, max_rows[1] ksw_global, whose
-// direction bits (ND/2 bytes per row and task, 64/G tasks per wavefront) must fit the LDS budget of a workgroup.
-struct L2Class { int nd, g, max_rows[2]; };
-constexpr L2Class L2_CLASS[NL2] = {{64, 16, {512, 160}}, {32, 8, {512, 128}}, {16, 4, {512, 128}},
-                                   {48, 4, {64, 40}},    {32, 2, {40, 24}},   {16, 1, {48, 32}}};
+// ksw_lane2_kernel's classes: ND band diagonals over G lanes.  A band width has a narrow form (few lanes per task: least
+// work per cell, long critical path) and a wide form (the task's critical path is (rows + G - 1) iterations of ND/G slots).
+// The launch is bound by instruction issue (profiles/r02_pmc_sq.csv: the VALU of every SIMD is busy ~87 % of the kernel),
+// so a task goes to the class where it costs the fewest wavefront instructions, (rows + G - 1) x L2_IPI / (64/G), among
+// those whose critical path (rows + G - 1) x L2_IPI stays below L2_LATCAP and whose LDS stays in budget; class 0 takes
+// what no other class can (up to L2_TCAP rows).  L2_IPI = instructions of one row-loop iteration, from the ISA listing.
+struct L2Class { int nd, g; };
+constexpr L2Class L2_CLASS[NL2] = {{64, 16}, {32, 8}, {16, 4}, {48, 4}, {32, 2}, {16, 1}, {8, 1}, {12, 1}, {40, 2}, {48, 2}, {24, 1}};
+// instructions of one row-loop iteration with C = ND/G slots per lane: a fit of the ISA listing (C = 4, 12, 16)
+constexpr int L2_IPI_BASE[3] = {58, 41, 110}, L2_IPI_SLOT[3] = {12, 22, 16};      // MODE_NW, MODE_GLOBAL, MODE_EXTEND
+inline int lane2_ipi(int mode, int k) { return L2_IPI_BASE[mode] + L2_IPI_SLOT[mode] * (L2_CLASS[k].nd / L2_CLASS[k].g); }
 size_t lane2_lds(int mode, int nd, int g, int tcap) {
     const size_t tpw = 64 / g;
     const size_t rw = (size_t)((tcap + nd + g + 8) >> 2) + 2;
     const size_t tw = (size_t)(tcap + g + 11) >> 2;
     return 64 + (rw + tw) * tpw * 4 + (mode == MODE_GLOBAL ? (size_t)(tcap + 1) * (nd / 4) * tpw * 2 : 0);
 }
-int lane2_class(int mode, const alfa_dp_params* p, const alfa_dp_task& x, int w) {
+int lane2_class(int mode, const alfa_dp_params* p, const alfa_dp_task& x, int w, int rows) {
     static const bool off = getenv("ALFA_DP_NO_LANE2") != nullptr;
-    if (off || p->m > QPAD || x.qlen < 1 || x.tlen < 1) return -1;
+    static const int64_t latcap_env = getenv("ALFA_DP_LATCAP") ? atoll(getenv("ALFA_DP_LATCAP")) : 0;
+    static const int64_t latcap_mode[3] = {16000, 16000, 24000};       // measured on the C3 stream (tools/dp_replay.py sweeps)
+    const int64_t latcap = latcap_env ? latcap_env : latcap_mode[mode];
+    static const size_t ldscap = getenv("ALFA_DP_LDSCAP") ? (size_t)atoll(getenv("ALFA_DP_LDSCAP")) : 24 * 1024;
+    if (off || p->m > QPAD || x.qlen < 1 || rows < 1) return -1;
     const int W = 2 * w + 1;
     if (W > 64) return -1;
     if (mode == MODE_EXTEND) {
@@ -1407,13 +1449,24 @@ int lane2_class(int mode, const alfa_dp_params* p, const alfa_dp_task& x, int w)
         for (int i = 0; i < p->m * p->m; ++i) maxs = std::max<int>(maxs, p->mat[i]);
         const int h0 = x.h0 < 0 ? 0 : x.h0;
         if ((int64_t)h0 + (int64_t)x.qlen * maxs >= (1 << 24)) return -1;
+        // the first-column value h0 - gapo - gape*(i+1) must stay positive for as long as the band touches column 0 (rows
+        // 0..w): once it is 0 the reference narrows the band from the left or not depending on E at the edge (ksw.c:435-436),
+        // which the static band of the fast kernel does not follow
+        if ((int64_t)h0 - p->gapo - (int64_t)p->gape * (w + 1) <= 0) return -1;
     } else if (std::abs(x.qlen - x.tlen) > w) return -1;         // "regular" tasks only (see the kernel's header comment)
-    // the narrowest class that holds the band and the target: classes 5, 4, 3 (narrow forms) before 2, 1, 0
-    static const int pref[NL2] = {5, 2, 4, 1, 3, 0};
-    for (int k : pref)
-        if (W <= L2_CLASS[k].nd && x.tlen <= L2_CLASS[k].max_rows[mode == MODE_GLOBAL]) return k;
-    if (mode == MODE_GLOBAL && x.tlen <= L2_TCAP) return NL2;   // class 0 with more LDS than the common launch is given
-    return -1;
+    int best = -1;
+    int64_t best_cost = 0;
+    for (int k = 1; k < NL2; ++k) {
+        const int g = L2_CLASS[k].g;
+        const int64_t path = (int64_t)(rows + g - 1) * lane2_ipi(mode, k);
+        if (W > L2_CLASS[k].nd || path > latcap || lane2_lds(mode, L2_CLASS[k].nd, g, rows) > ldscap) continue;
+        const int64_t cost = path * g;           // x 64 / (64/g) tasks per wavefront
+        if (best < 0 || cost < best_cost) { best = k; best_cost = cost; }
+    }
+    if (best >= 0) return best;
+    if (rows > L2_TCAP) return -1;
+    if (lane2_lds(mode, L2_CLASS[0].nd, L2_CLASS[0].g, rows) <= ldscap) return 0;
+    return mode == MODE_GLOBAL ? NL2 : -1;       // class 0 in a launch of its own, with more LDS than the common launch is given
 }
 
 template <int MODE, int C>
@@ -1434,11 +1487,11 @@ void launch_group(hipStream_t st, const DevTask* d_tasks, int n, const uint8_t* 
     if (!half_rows) {
         const int per_block = WPB * 4;
         hipLaunchKernelGGL((ksw_group_kernel<MODE, C, 16>), dim3((n + per_block - 1) / per_block), dim3(64 * WPB), 0, st, d_tasks, n, d_seq, d_prm,
-                           d_out, d_z, (const int*)nullptr);
+                           d_out, d_z);
     } else {
         const int per_block = WPB * 8;
         hipLaunchKernelGGL((ksw_group_kernel<MODE, 2 * C, 8>), dim3((n + per_block - 1) / per_block), dim3(64 * WPB), 0, st, d_tasks, n, d_seq, d_prm,
-                           d_out, d_z, (const int*)nullptr);
+                           d_out, d_z);
     }
 }
 
@@ -1476,11 +1529,14 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
     // Tasks of a bin are ordered by tlen, longest first: the first nbig direction matrices exceed ZC bytes (their backtrack
     // walks HBM), the rest fit ZC (LDS slices); the two backtrack classes of a bin run side by side.
     // streams: 0-2 group bins, 3-4 wave bins, 5-7 the LDS backtracks of the group bins
-    (void)hipEventRecord(cx->fork_ev, st);
+    // (the fork event is recorded at the first use of a side stream: nothing has been enqueued on `st` before that, and a
+    // batch whose tasks all run in ksw_lane2_kernel on `st` pays for no cross-stream dependency at all)
+    bool forked = false;
     bool used[alfa::Ctx::NSIDE] = {};
     static const int side_mod = [] { const char* e = getenv("ALFA_SIDE_STREAMS"); int v = e ? atoi(e) : alfa::Ctx::NSIDE; return v < 1 ? 1 : (v > alfa::Ctx::NSIDE ? alfa::Ctx::NSIDE : v); }();
     auto side = [&](int k) -> hipStream_t {
         k %= side_mod;
+        if (!forked) { (void)hipEventRecord(cx->fork_ev, st); forked = true; }
         if (!used[k]) { (void)hipStreamWaitEvent(cx->side[k], cx->fork_ev, 0); used[k] = true; }
         return cx->side[k];
     };
@@ -1525,18 +1581,17 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
     o += bc[7];
     const int o8 = o;
     o += bc[8];
-    // short tasks: a lane per task (ksw_lane2_kernel); ksw_extend tasks whose band starts to narrow come back in a list
-    // (count in word 0, task positions from word BAIL_HDR on) and run in the 16-lanes-per-task kernel on the same stream
+    // short tasks: band in registers (ksw_lane2_kernel); a ksw_extend task whose band starts to narrow is finished by its own
+    // wavefront with the moving-band code (wave_task) and counted in d_bail[0]
     {
-        int* d_bail = b->d_bail.as<int>();
+        int* d_cnt = b->d_bail.as<int>();
         int n_l2 = 0;
         for (int g = 0; g < NL2; ++g) n_l2 += bc[L2BIN + g];
         if (n_l2 + bc[L2BIN + NL2] > 0) {
-            // the give-up list's count is zero here (zeroed at create and again after every pass over the list)
-            hipStream_t s8 = side(8);
-            if (n_l2)
-                hipLaunchKernelGGL((ksw_lane2_kernel<MODE>), dim3(b->l2blocks), dim3(64), b->l2lds, s8, b->l2grid, d_t, d_seq, d_prm, d_out, d_cig,
-                                   d_ncig, d_bail);
+            // a synchronous call runs them on `st` (no cross-stream dependency: 25-45 us less per call); with lazy joins
+            // (alfa_set_lazy_join: the caller overlaps several batches and the seed kernels, which own `st`) on a side stream
+            hipStream_t s8 = cx->lazy_join ? side(8) : st;
+            // the long targets first: their few wavefronts are the longest-running ones
             if (b->l2big_blocks && b->l2big_lds > 48 * 1024) {
                 static std::atomic<bool> raised[64];
                 if (!raised[b->device & 63].exchange(true))
@@ -1544,13 +1599,11 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
             }
             if (b->l2big_blocks)
                 hipLaunchKernelGGL((ksw_lane2_kernel<MODE>), dim3(b->l2big_blocks), dim3(64), b->l2big_lds, side(9), b->l2big, d_t, d_seq, d_prm, d_out,
-                                   d_cig, d_ncig, d_bail);
-            if (MODE == MODE_EXTEND && n_l2) {
-                const int per_block = WPB * 4;
-                hipLaunchKernelGGL((ksw_group_kernel<MODE_EXTEND, 4, 16>), dim3((n_l2 + per_block - 1) / per_block), dim3(64 * WPB), 0, s8, d_t,
-                                   n_l2, d_seq, d_prm, d_out, d_z, (const int*)d_bail);
-                (void)hipMemsetAsync(d_bail, 0, sizeof(int) * BAIL_HDR, s8);
-            }
+                                   d_cig, d_ncig, d_cnt);
+            if (n_l2)
+                hipLaunchKernelGGL((ksw_lane2_kernel<MODE>), dim3(b->l2blocks), dim3(64), b->l2lds, s8, b->l2grid, d_t, d_seq, d_prm, d_out, d_cig,
+                                   d_ncig, d_cnt);
+            b->launches++;
         }
     }
     bool any = false;
@@ -1576,7 +1629,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
     b->dense_of.resize((size_t)n);
     if (!b->ev0) { ALFA_HIP(hipEventCreate(&b->ev0)); ALFA_HIP(hipEventCreate(&b->ev1)); }
     if (n == 0) return ALFA_OK;
-    std::vector<int> w_eff((size_t)n), bins((size_t)n), perm((size_t)n);
+    std::vector<int> w_eff((size_t)n), bins((size_t)n), perm((size_t)n), rows_eff((size_t)n);
     size_t seq_bytes = 0;
     // tasks of at most this many inner-loop iterations go to the lane-per-task kernel (0 = none); a lane runs its task
     // serially, so the bound caps the kernel's critical path
@@ -1586,6 +1639,9 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         if (x.qlen < 0 || x.tlen < 0 || x.w < 0) return alfa::fail(ALFA_EINVAL, "negative length or band in a DP task");
         if ((x.qlen > 0 && !x.query) || (x.tlen > 0 && !x.target)) return alfa::fail(ALFA_EINVAL, "null sequence pointer in a DP task");
         w_eff[i] = effective_w(mode, p, x);
+        // ksw_extend never gets past row qlen + w: there beg = i - w reaches qlen and the reference leaves its row loop
+        // (ksw.c:393-423), so the rows behind it are dropped here, for every kernel
+        rows_eff[i] = mode == MODE_EXTEND ? (int)std::min<int64_t>(x.tlen, (int64_t)x.qlen + w_eff[i] + 1) : x.tlen;
         int bin;
         if (x.qlen == 0 || x.tlen == 0) bin = 8;
         else if (lane_work > 0 && x.qlen <= 126 && (int64_t)x.tlen * std::min<int64_t>(x.qlen, 2 * (int64_t)w_eff[i] + 1) <= lane_work)
@@ -1593,13 +1649,13 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         else {
             const int W = 2 * w_eff[i] + 1;
             bin = W <= 16 ? 3 : W <= 32 ? 4 : W <= 64 ? 5 : W <= 128 ? 6 : W <= 256 ? 7 : 8;
-            const int l2 = lane2_class(mode, p, x, w_eff[i]);
+            const int l2 = lane2_class(mode, p, x, w_eff[i], rows_eff[i]);
             if (l2 >= 0) bin = L2BIN + l2;
         }
         bins[i] = bin;
         b->bin_cnt[bin]++;
-        if (bin >= 3 && bin <= 5 && (int64_t)x.tlen * (GL16 << (bin - 3)) > ZC) b->nbig[bin - 3]++;
-        if (bin >= 3 && bin <= 5 && x.tlen >= LONG_TLEN) b->nlong[bin - 3]++;
+        if (bin >= 3 && bin <= 5 && (int64_t)rows_eff[i] * (GL16 << (bin - 3)) > ZC) b->nbig[bin - 3]++;
+        if (bin >= 3 && bin <= 5 && rows_eff[i] >= LONG_TLEN) b->nlong[bin - 3]++;
         seq_bytes += (size_t)x.qlen + (size_t)x.tlen;
     }
     // order: by bin; inside a bin the most work first, so that the 64 tasks of a lane-kernel wave (and co-resident waves of the
@@ -1608,7 +1664,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
     std::vector<int64_t> work((size_t)n);
     for (int i = 0; i < n; ++i) {
         const alfa_dp_task& x = t[ids ? ids[i] : i];
-        work[i] = bins[i] < 3 ? (int64_t)x.tlen * std::min<int64_t>(x.qlen, 2 * (int64_t)w_eff[i] + 1) : (int64_t)x.tlen;
+        work[i] = bins[i] < 3 ? (int64_t)rows_eff[i] * std::min<int64_t>(x.qlen, 2 * (int64_t)w_eff[i] + 1) : (int64_t)rows_eff[i];
     }
     std::sort(perm.begin(), perm.end(), [&](int a, int c) {
         if (bins[a] != bins[c]) return bins[a] < bins[c];
@@ -1616,14 +1672,15 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         return a < c;
     });
     b->seq_bytes = seq_bytes;
-    if ((rc = cx->h_in.reserve(seq_bytes + 64)) || (rc = cx->h_tasks.reserve(sizeof(DevTask) * (size_t)n + sizeof(DevParams))) ||
-        (rc = b->d_seq.reserve(seq_bytes + 64)) || (rc = b->d_tasks.reserve(sizeof(DevTask) * (size_t)n + sizeof(DevParams))))
+    if ((rc = cx->h_in.reserve(seq_bytes + 96)) || (rc = cx->h_tasks.reserve(sizeof(DevTask) * (size_t)n + sizeof(DevParams))) ||
+        (rc = b->d_seq.reserve(seq_bytes + 96)) || (rc = b->d_tasks.reserve(sizeof(DevTask) * (size_t)n + sizeof(DevParams))))
         return rc;
     uint8_t* hs = cx->h_in.as<uint8_t>();
+    memset(hs, 0, 16);
     DevParams* hprm = cx->h_tasks.as<DevParams>();
     DevTask* ht = (DevTask*)(hprm + 1);
     *hprm = b->hp;
-    size_t so = 0;
+    size_t so = 16;      // ksw_lane2_kernel's staging reads up to 3 bytes in front of a sequence
     const int rowb[NBIN] = {0, 0, 0, GL16 * 1, GL16 * 2, GL16 * 4, 64 * 2, 64 * 4, 0};     // direction bytes per row (HBM); 0 for the lane2 bins
     const int m = b->hp.m;
     int bin_start[NBIN + 1] = {0};
@@ -1642,7 +1699,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         d.toff = (int64_t)so;
         for (int j = 0; j < x.tlen; ++j) { const uint8_t c = x.target[j]; if (c >= m) return alfa::fail(ALFA_EINVAL, "target residue code >= m"); hs[so + j] = c; }
         so += (size_t)x.tlen;
-        d.qlen = x.qlen; d.tlen = x.tlen; d.w = w_eff[li]; d.h0 = x.h0; d.orig = k;
+        d.qlen = x.qlen; d.tlen = rows_eff[li]; d.w = w_eff[li]; d.h0 = x.h0; d.orig = k;
         b->dense_of[k] = li;
         if (bins[li] == 8) { d.ehoff = b->eh_items; b->eh_items += (int64_t)x.qlen + 2; }
         if (mode == MODE_GLOBAL) {
@@ -1677,27 +1734,39 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         b->ht[k] = d;
     }
     // ksw_lane2_kernel's grid: the classes' blocks one after the other; LDS for the neediest class
+    // (the classes in the order of their longest wavefront's critical path, so that the launch does not end on one)
     int n_l2 = 0;
+    int order[NL2];
+    int64_t path[NL2];
     for (int g = 0; g < NL2; ++g) {
+        order[g] = g;
+        const int cnt = b->bin_cnt[L2BIN + g];
+        path[g] = cnt ? (int64_t)(b->ht[bin_start[L2BIN + g]].tlen + L2_CLASS[g].g - 1) * lane2_ipi(mode, g) : -1;
+    }
+    std::stable_sort(order, order + NL2, [&](int a, int c) { return path[a] > path[c]; });
+    for (int k = 0; k < NL2; ++k) {
+        const int g = order[k];
         const int s0 = bin_start[L2BIN + g], cnt = b->bin_cnt[L2BIN + g];
         const int tpw = 64 / L2_CLASS[g].g;
         n_l2 += cnt;
         b->l2blocks += (cnt + tpw - 1) / tpw;
-        b->l2grid.blk_end[g] = b->l2blocks;
-        b->l2grid.task_start[g] = s0;
-        b->l2grid.task_cnt[g] = cnt;
-        b->l2grid.tcap[g] = cnt ? b->ht[s0].tlen : 1;             // tasks of a bin are ordered longest target first
-        if (cnt) b->l2lds = std::max(b->l2lds, lane2_lds(mode, L2_CLASS[g].nd, L2_CLASS[g].g, b->l2grid.tcap[g]));
+        b->l2grid.blk_end[k] = b->l2blocks;
+        b->l2grid.task_start[k] = s0;
+        b->l2grid.task_cnt[k] = cnt;
+        b->l2grid.cls[k] = g;
+        b->l2grid.tcap[k] = cnt ? b->ht[s0].tlen : 1;             // tasks of a bin are ordered longest target first
+        if (cnt) b->l2lds = std::max(b->l2lds, lane2_lds(mode, L2_CLASS[g].nd, L2_CLASS[g].g, b->l2grid.tcap[k]));
     }
     if (b->bin_cnt[L2BIN + NL2]) {
         const int s0 = bin_start[L2BIN + NL2], cnt = b->bin_cnt[L2BIN + NL2], tpw = 64 / L2_CLASS[0].g;
         b->l2big_blocks = (cnt + tpw - 1) / tpw;
-        for (int g = 0; g < NL2; ++g) { b->l2big.blk_end[g] = b->l2big_blocks; b->l2big.task_start[g] = s0; b->l2big.task_cnt[g] = g ? 0 : cnt; b->l2big.tcap[g] = b->ht[s0].tlen; }
+        for (int g = 0; g < NL2; ++g) { b->l2big.blk_end[g] = b->l2big_blocks; b->l2big.task_start[g] = s0; b->l2big.task_cnt[g] = g ? 0 : cnt; b->l2big.tcap[g] = b->ht[s0].tlen; b->l2big.cls[g] = 0; }
         b->l2big_lds = lane2_lds(mode, L2_CLASS[0].nd, L2_CLASS[0].g, b->ht[s0].tlen);
     }
     if (mode == MODE_EXTEND && n_l2) {
-        if ((rc = b->d_bail.reserve(sizeof(int) * ((size_t)n_l2 + BAIL_HDR + 1)))) return rc;
-        ALFA_HIP(hipMemsetAsync(b->d_bail.p, 0, sizeof(int) * BAIL_HDR, cx->stream));       // synchronised with the copies below
+        if ((rc = b->d_bail.reserve(256))) return rc;
+        ALFA_HIP(hipMemsetAsync(b->d_bail.p, 0, 256, cx->stream));       // synchronised with the copies below
+        b->launches = 0;
     }
     b->out_bytes = (mode == MODE_EXTEND ? sizeof(ExtOut) : sizeof(int32_t)) * (size_t)n;
     if ((rc = b->d_out.reserve(b->out_bytes)) || (rc = b->h_out.reserve(b->out_bytes))) return rc;
@@ -1707,7 +1776,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         if ((rc = b->d_z.reserve((size_t)b->zbytes + 64)) || (rc = b->d_cig.reserve(cb)) || (rc = b->h_cig.reserve(cb))) return rc;
     }
     hipStream_t st = cx->stream;
-    ALFA_HIP(hipMemcpyAsync(b->d_seq.p, hs, seq_bytes, hipMemcpyHostToDevice, st));
+    ALFA_HIP(hipMemcpyAsync(b->d_seq.p, hs, seq_bytes + 16, hipMemcpyHostToDevice, st));
     ALFA_HIP(hipMemcpyAsync(b->d_tasks.p, hprm, sizeof(DevParams) + sizeof(DevTask) * (size_t)n, hipMemcpyHostToDevice, st));
     ALFA_HIP(hipStreamSynchronize(st));   // staging buffers of the context are free again
     return ALFA_OK;
@@ -1896,8 +1965,8 @@ int64_t alfa_dp_batch_giveups(alfa_dp_batch* b, int64_t* n_fast) {
     if (b->mode != MODE_EXTEND || n_l2 == 0 || !b->launched) return 0;
     if (alfa_sync(b->device) != ALFA_OK) return -1;
     int cnt = 0;
-    if (hipMemcpy(&cnt, b->d_bail.as<int>() + BAIL_HDR + n_l2, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    return cnt;
+    if (hipMemcpy(&cnt, b->d_bail.as<int>(), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return cnt / (b->launches > 0 ? b->launches : 1);      // every launch of a batch gives up on the same tasks
 }
 double alfa_dp_batch_kernel_ms(const alfa_dp_batch* b) {
     if (!b || !b->launched || b->n == 0) return 0;

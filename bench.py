@@ -350,6 +350,7 @@ def main():
     timed_nw = timed[0][2].fetch()
     timed_gl = timed[0][3].fetch()
     fast_tasks = {"extend": timed[0][1].giveups(), "nw": timed[0][2].giveups(), "global": timed[0][3].giveups()}
+    giveups_each = [st[1].giveups()[1] for st in timed]
 
     # PCIe-inclusive rate: create (host packing + H2D) + launch + fetch (D2H + unpacking) of the first step, through the
     # synchronous halves of the C ABI.  Never `value`.
@@ -537,6 +538,7 @@ def main():
                  "inner-loop iterations of ksw_extend (SURVEY 8d) are executed_over_envelope x that (oracle counter on the CPU sample)",
         "extend_executed_over_envelope": executed_ratio,
         "band_in_registers_tasks_and_giveups": fast_tasks,
+        "extend_giveups_per_step": giveups_each,
         "timing": "each batch of the timed steps launched once more by itself, HIP events around its kernels",
     }
     occupancy = None
@@ -591,9 +593,9 @@ def main():
         "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
         "dp_gcups": (cells_ext + cells_nw + cells_gl) / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else None,
         "dp_detail": {
-            "extend": {"cells": cells_ext, "ms": sum(ext_ms), "gcups": cells_ext / max(sum(ext_ms), 1e-9) / 1e6},
-            "nw": {"cells": cells_nw, "ms": sum(nw_ms), "gcups": cells_nw / max(sum(nw_ms), 1e-9) / 1e6},
-            "global": {"cells": cells_gl, "ms": sum(gl_ms), "gcups": cells_gl / max(sum(gl_ms), 1e-9) / 1e6},
+            "extend": {"cells": cells_ext, "ms": sum(ext_ms), "gcups": cells_ext / max(sum(ext_ms), 1e-9) / 1e6, "ms_each": [round(x, 4) for x in ext_ms]},
+            "nw": {"cells": cells_nw, "ms": sum(nw_ms), "gcups": cells_nw / max(sum(nw_ms), 1e-9) / 1e6, "ms_each": [round(x, 4) for x in nw_ms]},
+            "global": {"cells": cells_gl, "ms": sum(gl_ms), "gcups": cells_gl / max(sum(gl_ms), 1e-9) / 1e6, "ms_each": [round(x, 4) for x in gl_ms]},
         },
         "roofline_dp": roofline_dp,
         "seed_queries_per_step": queries_per_step,

@@ -63,3 +63,28 @@ def test_empty_batch(gpu):
     tasks, keep = ffi.make_dp_tasks([], 0, 0)
     assert len(ffi.ksw_extend_batch(P, tasks)) == 0
     assert len(ffi.ksw_nw_batch(P, tasks)) == 0
+
+
+def test_extend_dead_boundary_cells(gpu):
+    """ksw_extend with h0 too small for the band: row -1 holds zeros inside the band (dead cells, ksw.c:403 extends nothing out
+    of them).  Low-complexity sequences make the diagonals that start in a dead cell score as well as the main one -- the
+    band-in-registers kernel must not revive them (it gives such tasks to the moving-band code)."""
+    rng = np.random.default_rng(5)
+    pairs, ws, hs = [], [], []
+    for _ in range(6000):
+        h0, w, n = int(rng.integers(1, 30)), int(rng.integers(1, 24)), int(rng.integers(6, 60))
+        a = int(rng.integers(0, 4))
+        x = (a + 1 + int(rng.integers(0, 3))) % 4
+        unit = rng.integers(0, 4, int(rng.integers(1, 4)))
+        body = np.resize(unit, n)
+        body = np.where(rng.random(n) < 0.1, rng.integers(0, 4, n), body)
+        lead = int(rng.integers(1, w + 1))
+        q = np.concatenate([[x], [a] * lead, body]).astype(np.uint8)
+        sh = int(rng.integers(1, lead + 1))
+        t = np.concatenate([[a], q[sh + 1:], rng.integers(0, 4, int(rng.integers(0, 6)))]).astype(np.uint8)
+        pairs.append((q, t)); ws.append(w); hs.append(h0)
+    P = ffi.default_params()
+    tasks, keep = ffi.make_dp_tasks(pairs, ws, hs)
+    e, eo = ffi.ksw_extend_batch(P, tasks), O.orc_ksw_extend_batch(P, tasks)
+    bad = np.nonzero(e != eo)[0]
+    assert len(bad) == 0, [(int(i), ws[i], hs[i], e[i], eo[i]) for i in bad[:5]]
