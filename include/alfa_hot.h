@@ -195,8 +195,8 @@ int     alfa_dp_batch_launch(alfa_dp_batch*);
 /* out: alfa_extend_result[n] (EXTEND) or int32 score[n]; cigar/n_cigar/cig_off as alfa_ksw_global_batch (GLOBAL only, else NULL) */
 int     alfa_dp_batch_fetch(alfa_dp_batch*, void* out, uint32_t** cigar, int32_t* n_cigar, int64_t* cig_off);
 int64_t alfa_dp_batch_cells(const alfa_dp_batch*);       /* inner-loop cells of the static band envelope */
-/* diagnostics: *n_fast = tasks of the batch that run in the band-in-registers kernel; returns how many ksw_extend tasks of the
- * last launch left it for the row-per-16-lanes kernel because their band started to narrow (synchronises; -1 on error) */
+/* diagnostics: *n_fast = tasks of the batch that run in the band-in-registers kernel; returns how many ksw_extend tasks of a
+ * launch gave up there because their band started to narrow and were finished by the moving-band code (synchronises; -1 on error) */
 int64_t alfa_dp_batch_giveups(alfa_dp_batch*, int64_t* n_fast);
 double  alfa_dp_batch_kernel_ms(const alfa_dp_batch*);   /* HIP-event time of the last launch's kernels (after fetch/sync) */
 void    alfa_dp_batch_free(alfa_dp_batch*);
