@@ -977,8 +977,9 @@ __global__ __launch_bounds__(64) void ksw_lane_kernel(const DevTask* __restrict_
 //   * ksw_extend: row maximum and its LAST column (ksw.c:414) are one packed key per slot, (H - gapoe) << 6 | slot;
 //     gscore / max_ie need H(i, qlen-1) of every row: a diagonal that leaves the matrix through the last column is frozen
 //     there, so they are read off the registers once, after the last row.  The kernel only follows the STATIC band: the
-//     band of ksw_extend narrows only where an in-band H is 0 (ksw.c:435-438), so a task that meets one (or a zero
-//     first-column value) gives up and is appended to a list that the row-per-16-lanes kernel then runs.
+//     band of ksw_extend narrows only where an in-band H is 0 (ksw.c:435-438), so a task that meets one gives up and is
+//     finished at once by its own wavefront with the moving-band code (wave_task).  Tasks whose first-column value reaches 0
+//     while the band touches column 0 are kept out by lane2_class; zeros of row -1 are preloaded as DEAD.
 //   * ksw_global: four direction BITS per cell (sign bits of the four comparisons, shifted in with v_alignbit) go to LDS,
 //     16 bits per 4 slots, and lane 0 of the task walks them back right after the last row: no direction bytes in HBM, no
 //     second kernel.  Only "regular" tasks come here (|qlen - tlen| <= w, both lengths >= 1): every in-band cell then has
