@@ -126,6 +126,51 @@ void HotSched::flush() {
         }
         seed_.clear();
     }
+    if (!seedreg_.empty()) {
+        // one call per (seed type, region parameters): the parameters are per mapper, so per type in practice
+        for (int type = 0; type < 4; ++type) {
+            std::vector<alfa_seed_query> q;
+            std::vector<int32_t> ed;
+            std::vector<size_t> who;
+            for (size_t i = 0; i < seedreg_.size(); ++i)
+                if (seedreg_[i].mem_type == type) {
+                    const SeedRegionReq& r = seedreg_[i];
+                    q.push_back(alfa_seed_query{r.P->data(), (int32_t)r.P->size(), r.min_len, r.max_count, r.sparse_q, r.max_smem});
+                    ed.push_back(r.edit_dist);
+                    who.push_back(i);
+                }
+            if (q.empty()) continue;
+            const size_t nq = q.size();
+            alfa_match *m = nullptr, *mem = nullptr;
+            alfa_region* reg = nullptr;
+            std::vector<int64_t> off(nq + 1), roff(nq + 1), boff(nq + 1);
+            std::vector<int32_t> st(nq);
+            int rc = ops_.seed_regions_batch(ops_.index, type, q.data(), ed.data(), (int)nq, &seedreg_[who[0]].prm, &m, off.data(), &reg, roff.data(),
+                                             &mem, boff.data(), st.data());
+            if (rc) die(ops_, "alfa_seed_regions_batch", rc);
+            for (size_t k = 0; k < nq; ++k) {
+                const SeedRegionReq& r = seedreg_[who[k]];
+                static_assert(sizeof(Match) == sizeof(alfa_match), "Match == alfa_match");
+                r.out->resize((size_t)(off[k + 1] - off[k]));
+                if (off[k + 1] > off[k]) memcpy((void*)r.out->data(), m + off[k], sizeof(Match) * (size_t)(off[k + 1] - off[k]));
+                *r.status = st[k];
+                r.regions->clear();
+                if (st[k] == 0) {
+                    r.regions->resize((size_t)(roff[k + 1] - roff[k]));
+                    for (int64_t j = roff[k]; j < roff[k + 1]; ++j) {
+                        RegionOut& o = (*r.regions)[(size_t)(j - roff[k])];
+                        o.refBegin = reg[j].ref_begin; o.refEnd = reg[j].ref_end; o.score = reg[j].score;
+                        o.matches.resize((size_t)reg[j].count);
+                        memcpy((void*)o.matches.data(), mem + boff[k] + reg[j].first, sizeof(Match) * (size_t)reg[j].count);
+                    }
+                }
+            }
+            ops_.free_fn(m); ops_.free_fn(reg); ops_.free_fn(mem);
+            stats_.seed_calls++;
+            stats_.seed_queries += (int64_t)nq;
+        }
+        seedreg_.clear();
+    }
     if (!nw_.empty()) {
         std::vector<alfa_dp_task> t(nw_.size());
         std::vector<int32_t> s(nw_.size());

@@ -23,6 +23,9 @@ namespace alfa {
 struct HotOps {
     void* index = nullptr;   // alfa_index* (what seed_batch expects as its first argument)
     int (*seed_batch)(void*, int, const alfa_seed_query*, int, alfa_match**, int64_t*) = nullptr;
+    // optional: seeds and the candidate regions built from them in one call; nullptr = the mapper builds them
+    int (*seed_regions_batch)(void*, int, const alfa_seed_query*, const int32_t*, int, const alfa_region_params*, alfa_match**, int64_t*,
+                              alfa_region**, int64_t*, alfa_match**, int64_t*, int32_t*) = nullptr;
     int (*ksw_extend_batch)(const alfa_dp_params*, const alfa_dp_task*, int, alfa_extend_result*) = nullptr;
     int (*ksw_nw_batch)(const alfa_dp_params*, const alfa_dp_task*, int, int32_t*) = nullptr;
     int (*ksw_global_batch)(const alfa_dp_params*, const alfa_dp_task*, int, int32_t*, uint32_t**, int32_t*, int64_t*) = nullptr;
@@ -35,6 +38,13 @@ struct Match { int64_t ref; int32_t query; int32_t len; };   // == match_t / alf
 
 struct SeedReq {
     const std::string* P; int min_len, max_count, sparse_q, mem_type, max_smem; std::vector<Match>* out;
+};
+// a region as identifyAndFilter + coveredBases leave it (lis_t without the bookkeeping fields)
+struct RegionOut { int64_t refBegin, refEnd; int score; std::vector<Match> matches; };
+// one strand: seeds and, when the hot path could build them (*status == 0), its candidate regions in creation order
+struct SeedRegionReq {
+    const std::string* P; int min_len, max_count, sparse_q, mem_type, max_smem, edit_dist; alfa_region_params prm;
+    std::vector<Match>* out; std::vector<RegionOut>* regions; int* status;
 };
 struct ExtendReq { alfa_dp_task t; alfa_extend_result* out; };
 struct NwReq { alfa_dp_task t; int32_t* out; };
@@ -56,6 +66,8 @@ class HotSched {
 
     // ---- called from inside a job
     void submit_seed(const SeedReq& r) { seed_.push_back(r); }
+    void submit_seed_regions(const SeedRegionReq& r) { seedreg_.push_back(r); }
+    bool has_seed_regions() const { return ops_.seed_regions_batch != nullptr; }
     void submit_extend(const ExtendReq& r) { ext_.push_back(r); }
     void submit_nw(const NwReq& r) { nw_.push_back(r); }
     void submit_global(const GlobalReq& r) { glob_.push_back(r); }
@@ -81,6 +93,7 @@ class HotSched {
     int current_ = -1;
     const std::function<void(int)>* job_ = nullptr;
     std::vector<SeedReq> seed_;
+    std::vector<SeedRegionReq> seedreg_;
     std::vector<ExtendReq> ext_;
     std::vector<NwReq> nw_;
     std::vector<GlobalReq> glob_;

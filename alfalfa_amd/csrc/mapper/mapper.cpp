@@ -341,6 +341,47 @@ void Mapper::cand_regions(const Read& read, std::vector<Lis>& lis, double errorP
     if (!opt_.fixedMinLength && Plength >= 1000) min_len += (20 * ((int)(Plength / 500))) / ((int)100 * errorPercent);
     if (opt_.fixedMinLength && Plength / editDist > min_len) min_len = Plength / editDist;
     std::vector<Match> matches, matchesRC;
+    if (opt_.deviceRegions && hot_.has_seed_regions()) {
+        // the hot path returns the seeds AND the regions built from them (alfa_seed_regions_batch); strands it hands back
+        // (status 1) and the rescue rounds' control flow stay here.  Same requests, same rounds as seeds_both_strands.
+        std::vector<RegionOut> regF, regR;
+        int stF = 0, stR = 0;
+        const int K = (int)idx_.K();
+        int sparseSkip = K >= 4 ? std::max((min_len - 10) / K, 1) : std::max((min_len - 12) / K, 1);
+        if (opt_.noSparseQ) sparseSkip = 1;
+        const alfa_region_params rp{opt_.maxSeedCandidates, opt_.maxRegionMems, opt_.minMemRegLength};
+        auto both = [&](int ml, int maxBranch, int skip) {
+            if (!opt_.noFW) hot_.submit_seed_regions(SeedRegionReq{&P, ml, maxBranch, skip, opt_.memType, opt_.maxSmemMemStart, editDist, rp, &matches, &regF, &stF});
+            if (!opt_.noRC) hot_.submit_seed_regions(SeedRegionReq{&Prc, ml, maxBranch, skip, opt_.memType, opt_.maxSmemMemStart, editDist, rp, &matchesRC, &regR, &stR});
+            hot_.wait();
+        };
+        both(min_len, opt_.maxSeedCandidates, sparseSkip);
+        if (opt_.rescue && matches.empty() && matchesRC.empty()) {
+            int minLength = std::max(MIN_SEED_LENGTH, K + 10);
+            both((minLength + min_len) / 2, 100000, 1);
+            if (matches.empty() && matchesRC.empty()) both(minLength, 100000, 1);
+        }
+        if (matches.size() > 0 || matchesRC.size() > 0) {
+            auto take = [&](std::vector<Match>& mm, std::vector<RegionOut>& rg, int st, bool fw) {
+                if (st != 0) {
+                    const size_t first = lis.size();
+                    identify_and_filter(mm, fw, Plength, editDist, lis);
+                    for (size_t i = first; i < lis.size(); i++) lis[i].score = covered_bases(lis[i].matches);
+                    return;
+                }
+                for (RegionOut& r : rg) {
+                    lis.push_back(Lis());
+                    Lis& l = lis.back();
+                    l.fw = fw; l.refBegin = r.refBegin; l.refEnd = r.refEnd; l.score = r.score;
+                    l.matches.swap(r.matches);
+                }
+            };
+            take(matches, regF, stF, true);
+            take(matchesRC, regR, stR, false);
+            std::sort(lis.begin(), lis.end(), [](const Lis& a, const Lis& b) { return a.score > b.score; });   // compIntervals :1114
+        }
+        return;
+    }
     seeds_both_strands(P, Prc, min_len, matches, matchesRC);
     if (matches.size() > 0 || matchesRC.size() > 0) {
         identify_and_filter(matches, true, Plength, editDist, lis);

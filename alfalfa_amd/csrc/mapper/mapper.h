@@ -34,6 +34,7 @@ struct AlignOpt {                 // align_opt, defaults of mapOptions_t::initOp
     int memType = SEED_SMAM;
     int fixedBandSize = 100;
     int maxAlnCount = 5000;
+    bool deviceRegions = false;   // --device-regions: identifyAndFilter + coveredBases run on the hot path's side
     void fill_m();                // align_opt::fill_m src/options.cpp:33-41
 };
 

@@ -114,6 +114,7 @@ bool parse(int argc, char** argv, Options& o) {
         else if (is(nullptr, "device")) o.device = atoi(need(i));
         else if (is(nullptr, "stats")) o.stats = true;
         else if (is(nullptr, "gpu-index")) o.gpuIndex = true;
+        else if (is(nullptr, "device-regions")) o.aln.deviceRegions = true;
         else { fprintf(stderr, "ERROR: unknown option %s\n", a.c_str()); exit(1); }
     }
     if (o.command == "index") {

@@ -34,6 +34,13 @@ class Match(C.Structure):
 MATCH_DTYPE = np.dtype([("ref", "<i8"), ("query", "<i4"), ("len", "<i4")])
 
 
+REGION_DTYPE = np.dtype([("ref_begin", "<i8"), ("ref_end", "<i8"), ("score", "<i4"), ("first", "<i4"), ("count", "<i4"), ("reserved", "<i4")])
+
+
+class RegionParams(C.Structure):
+    _fields_ = [("max_seed_candidates", C.c_int32), ("max_region_mems", C.c_int32), ("min_mem_reg_length", C.c_int32)]
+
+
 class SeedQuery(C.Structure):
     _fields_ = [("P", C.c_char_p), ("plen", C.c_int32), ("min_len", C.c_int32), ("max_count", C.c_int32),
                 ("sparse_q", C.c_int32), ("max_smem_cont", C.c_int32)]
@@ -296,6 +303,26 @@ class DeviceIndex:
             check(rc)
             return rc
         return _seed_call(fn, self._h, mem_type, queries, lib().alfa_free)
+
+    def seed_regions_batch(self, mem_type, queries, edit_dist, max_seed_candidates=10000, max_region_mems=20, min_mem_reg_length=50):
+        """alfa_seed_regions_batch: (matches, match_off, regions, region_off, members, member_off, status)"""
+        nq = len(queries)
+        ed = np.ascontiguousarray(edit_dist, dtype=np.int32)
+        prm = RegionParams(int(max_seed_candidates), int(max_region_mems), int(min_mem_reg_length))
+        m, r, mb = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        moff, roff, boff = (np.zeros(nq + 1, dtype=np.int64) for _ in range(3))
+        status = np.zeros(max(nq, 1), dtype=np.int32)
+        L = lib()
+        L.alfa_seed_regions_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 7
+        check(L.alfa_seed_regions_batch(self._h, int(mem_type), C.cast(queries, C.c_void_p), ed.ctypes.data_as(C.c_void_p), nq, C.byref(prm),
+                                        C.byref(m), moff.ctypes.data_as(C.c_void_p), C.byref(r), roff.ctypes.data_as(C.c_void_p),
+                                        C.byref(mb), boff.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p)))
+
+        def take(ptr, count, dt):
+            out = np.frombuffer(C.string_at(ptr.value, int(count) * dt.itemsize), dtype=dt).copy() if count else np.zeros(0, dtype=dt)
+            L.alfa_free(ptr)
+            return out
+        return (take(m, moff[nq], MATCH_DTYPE), moff, take(r, roff[nq], REGION_DTYPE), roff, take(mb, boff[nq], MATCH_DTYPE), boff, status[:nq])
 
     def __del__(self):
         try:

@@ -118,6 +118,23 @@ int  alfa_index_device(const alfa_index*);
 int  alfa_seed_batch(alfa_index*, int mem_type, const alfa_seed_query* q, int nq,
                      alfa_match** matches, int64_t* offsets);
 
+/* --- seeds -> candidate regions ----------------------- */
+/* replaces, for nq independent read strands: executeSeedType followed by identifyAndFilter (src/mapper.cpp:578-704) and
+ * coveredBases (:706-719, the score calculateCandRegions gives every region, :1262).  The matches stay on the device
+ * between the two steps.  For strand i (qLength = q[i].plen, editDist = edit_dist[i]):
+ *   (*matches)[match_off[i] .. match_off[i+1])      the seeds, as alfa_seed_batch returns them
+ *   status[i] == 0: (*regions)[region_off[i] .. region_off[i+1]) are its regions in the order identifyAndFilter creates
+ *                   them; region r owns (*members)[member_off[i] + r.first .. + r.count), sorted as coveredBases leaves them
+ *   status[i] == 1: the strand is left to the caller (more matches or regions than the kernel holds, or matches that compare
+ *                   equal under the reference's comparators but differ: std::sort's order of those cannot be reproduced)
+ * match_off, region_off, member_off have nq+1 entries, status nq (caller-allocated); the three arrays are library-allocated
+ * (alfa_free).  p: maxSeedCandidates, maxRegionMems, minMemRegLength (alnOptions, src/options.h). */
+typedef struct { int64_t ref_begin, ref_end; int32_t score, first, count, reserved; } alfa_region;
+typedef struct { int32_t max_seed_candidates, max_region_mems, min_mem_reg_length; } alfa_region_params;
+int  alfa_seed_regions_batch(alfa_index*, int mem_type, const alfa_seed_query* q, const int32_t* edit_dist, int nq,
+                             const alfa_region_params* p, alfa_match** matches, int64_t* match_off,
+                             alfa_region** regions, int64_t* region_off, alfa_match** members, int64_t* member_off, int32_t* status);
+
 /* --- banded DP ---------------------------------------------------------- */
 /* replaces: ksw_extend(...)  src/ksw.h:106 / src/ksw.c:362 */
 int  alfa_ksw_extend_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, alfa_extend_result* r);
