@@ -279,16 +279,23 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
             }
             // ---- band shrink (ksw.c:435-438) in terms of this row's H values:
             //   eh[j].h == H(i,j-1) for beg<j<=end, eh[beg].h == h1_init
+            // (an in-band zero is rare while the extension is alive: the two reductions run only when a lane holds one)
+            bool lane_zero = false;
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int j = base + lane * C + c;
-                if (act[c] && Hrow[c] == 0) {
-                    if (j <= mjrow - 1) zl_l = j;                       // slots ascend with c: keeps the largest
-                    if (j >= mjrow + 1 && j < zr_l) zr_l = j;
+            for (int c = 0; c < C; ++c) lane_zero |= act[c] & (Hrow[c] == 0);
+            int zl = -1, zr = 0x7fffffff;
+            if (__ballot(lane_zero)) {          // wave-uniform
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int j = base + lane * C + c;
+                    if (act[c] && Hrow[c] == 0) {
+                        if (j <= mjrow - 1) zl_l = j;                       // slots ascend with c: keeps the largest
+                        if (j >= mjrow + 1 && j < zr_l) zr_l = j;
+                    }
                 }
+                zl = wave_max(zl_l);
+                zr = wave_min(zr_l);
             }
-            const int zl = wave_max(zl_l);
-            const int zr = wave_min(zr_l);
             // inject H(i, beg-1) := h1_init on the diagonal just left of the band (read by row i+1 if beg stays)
             {
                 const int di = db - 1;
@@ -575,17 +582,22 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
                 h1 = grp_max<GL>(hv);
             }
             int zl = -1, zr = 0x7fffffff;
+            bool lane_zero = false;
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int j = base + gl * C + c;
-                const int mjrow_l = m < 0 ? -1 : mj;
-                if (act[c] && Hrow[c] == 0) {
-                    if (j <= mjrow_l - 1) zl_l = j;
-                    if (j >= mjrow_l + 1 && j < zr_l) zr_l = j;
+            for (int c = 0; c < C; ++c) lane_zero |= act[c] & (Hrow[c] == 0);
+            if (__ballot(lane_zero & live)) {   // wave-uniform; in-band zeros are rare while an extension is alive
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int j = base + gl * C + c;
+                    const int mjrow_l = m < 0 ? -1 : mj;
+                    if (act[c] && Hrow[c] == 0) {
+                        if (j <= mjrow_l - 1) zl_l = j;
+                        if (j >= mjrow_l + 1 && j < zr_l) zr_l = j;
+                    }
                 }
+                zl = grp_max<GL>(zl_l);
+                zr = grp_min<GL>(zr_l);
             }
-            zl = grp_max<GL>(zl_l);
-            zr = grp_min<GL>(zr_l);
             if (live) {
                 if (jfin == qlen) {
                     max_ie = gscore > h1 ? max_ie : i;
