@@ -393,10 +393,11 @@ def main():
     # valid only for the batch size it was collected at; null otherwise
     traffic = None
     try:
-        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
+                      if f.endswith("_pmc_traffic.json") and (f.endswith("_c4_pmc_traffic.json") == c4))
         if prof:
             pj = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
-            if pj.get("batch") == args.batch and args.ref_len == 5000000 and args.read_len == 250:
+            if pj.get("batch") == args.batch and (c4 or (args.ref_len == 5000000 and args.read_len == 250)):
                 traffic = pj["bytes_per_dispatch"].get("smam_count_kernel")
     except Exception:
         traffic = None
@@ -612,6 +613,9 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic else None,
+            "traffic_gbs": (traffic / (seed_avg_ms * 1e-3) / 1e9) if traffic else None,
+            "traffic_gbs_isolated": (traffic / (float(np.mean(seed_iso_ms)) * 1e-3) / 1e9) if traffic else None,
             "traffic_note": "raw FETCH_SIZE x 1024 per dispatch (profiles/*_pmc_traffic.json, the latest round). Calibrated on this access pattern "
                             "(tools/fetch_calib.hip, profiles/r01_fetch_calibration.csv): an isolated 4/8/16-byte gather from a 2 GiB "
                             "table tallies 64 B, a wide streaming read tallies half its bytes (the guide's x2 case); the seed "
