@@ -704,13 +704,17 @@ __global__ void ksw_backtrack_kernel(const DevTask* __restrict__ tasks, int ntas
 }
 
 // Same walk for long tasks, one wavefront per task: the direction matrix is pulled through LDS in tiles of TILE_ROWS rows with
-// coalesced 16-byte loads by all lanes, and lane 0 walks inside the tile -- one HBM round trip per tile instead of one per
-// step (a 5 kbp x 5 kbp alignment is ~10^4 dependent steps: ~10 ms walking HBM, the critical path of a long-read batch).
+// coalesced 16-byte loads by all lanes -- one HBM round trip per tile instead of one per step (a 5 kbp x 5 kbp alignment is ~10^4
+// dependent steps: ~10 ms walking HBM, the critical path of a long-read batch) -- and the walk inside a tile takes a whole
+// DIAGONAL RUN per step: in the match state lane t looks at the cell t steps up the diagonal, a ballot finds the first cell
+// that leaves it, and the run is pushed as one CIGAR piece (gaps are ~25 residues apart at 10 % error; the walk was one
+// dependent LDS read per residue).  Every lane carries the same walk state; lane 0 writes.  Tile rows are padded by 16 bytes
+// so that a diagonal (stride one row) spreads over the LDS banks.
 constexpr int TILE_ROWS = 64;
 constexpr int LONG_TLEN = 512;        // from this many rows on, the tiled walk beats one lane per task walking HBM
 __global__ __launch_bounds__(64) void ksw_backtrack_tile_kernel(const DevTask* __restrict__ tasks, int ntask, const uint8_t* __restrict__ zbuf,
                                                                uint32_t* __restrict__ cig, int32_t* __restrict__ ncig, int ROWB) {
-    __shared__ uint4 tile[TILE_ROWS * 256 / 16];                 // ROWB <= 256
+    __shared__ uint4 tile[TILE_ROWS * (256 + 16) / 16];          // ROWB <= 256
     const int t = blockIdx.x;
     if (t >= ntask) return;
     const int lane = threadIdx.x;
@@ -722,39 +726,53 @@ __global__ __launch_bounds__(64) void ksw_backtrack_tile_kernel(const DevTask* _
     uint32_t cur_op = 0xffffffffu, cur_len = 0;
     auto push = [&](uint32_t op, uint32_t len) {
         if (op == cur_op) { cur_len += len; return; }
-        if (cur_op != 0xffffffffu) { slot[--pos] = cur_len << 4 | cur_op; ++n; }
+        if (cur_op != 0xffffffffu) { --pos; if (lane == 0) slot[pos] = cur_len << 4 | cur_op; ++n; }
         cur_op = op; cur_len = len;
     };
     int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
     int which = 0;
     const uint8_t* z = zbuf + T.zoff;                            // 16-byte aligned, rows of ROWB (a multiple of 16) bytes
     const int v_per_row = ROWB >> 4;
-    while (i >= 0 && k >= 0) {                                   // i, k are uniform: lane 0's values are broadcast after each tile
+    const int TROW = ROWB + 16;                                  // bytes of a tile row in LDS
+    const uint8_t* zt = (const uint8_t*)tile;
+    while (i >= 0 && k >= 0) {                                   // i, k, which are wave-uniform throughout
         const int lo = i - TILE_ROWS + 1 > 0 ? i - TILE_ROWS + 1 : 0;
         const int nv = (i - lo + 1) * v_per_row;
         const uint4* src = (const uint4*)(z + (int64_t)lo * ROWB);
-        for (int x = lane; x < nv; x += 64) tile[x] = src[x];
+        for (int x = lane; x < nv; x += 64) {
+            const int r = x / v_per_row, c = x - r * v_per_row;
+            tile[r * (v_per_row + 1) + c] = src[x];
+        }
         __syncthreads();
-        if (lane == 0) {
-            const uint8_t* zt = (const uint8_t*)tile;
-            while (i >= lo && k >= 0) {
-                const uint32_t zv = zt[(i - lo) * ROWB + (k - i + w)];
+        while (i >= lo && k >= 0) {
+            const int d = k - i + w;
+            if (which == 0) {
+                int avail = i - lo + 1;
+                avail = avail < k + 1 ? avail : k + 1;
+                avail = avail < 64 ? avail : 64;
+                const uint32_t zv = lane < avail ? zt[(i - lane - lo) * TROW + d] : 1u;
+                const uint64_t stay = __ballot((zv & 3u) == 0u);
+                const int run = stay == ~0ull ? 64 : __builtin_ctzll(~stay);       // <= avail: the lanes beyond it report "leaves"
+                if (run > 0) { push(0, (uint32_t)run); i -= run; k -= run; }
+                if (run < avail) {
+                    which = (int)(__shfl((int)zv, run, 64) & 3);
+                    if (which == 1) { push(2, 1); --i; }
+                    else { push(1, 1); --k; }
+                }
+            } else {
+                const uint32_t zv = zt[(i - lo) * TROW + d];
                 which = (zv >> (which << 1)) & 3;
                 if (which == 0) { push(0, 1); --i; --k; }
                 else if (which == 1) { push(2, 1); --i; }
                 else { push(1, 1); --k; }
             }
         }
-        i = __shfl(i, 0, 64);
-        k = __shfl(k, 0, 64);
         __syncthreads();
     }
-    if (lane == 0) {
-        if (i >= 0) push(2, (uint32_t)(i + 1));
-        if (k >= 0) push(1, (uint32_t)(k + 1));
-        if (cur_op != 0xffffffffu) { slot[--pos] = cur_len << 4 | cur_op; ++n; }
-        ncig[T.orig] = n;
-    }
+    if (i >= 0) push(2, (uint32_t)(i + 1));
+    if (k >= 0) push(1, (uint32_t)(k + 1));
+    if (cur_op != 0xffffffffu) { --pos; if (lane == 0) slot[pos] = cur_len << 4 | cur_op; ++n; }
+    if (lane == 0) ncig[T.orig] = n;
 }
 
 // Same walk for small tasks (direction matrix of at most ZC bytes): every lane first copies its task's matrix into its own
