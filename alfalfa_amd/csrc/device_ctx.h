@@ -62,7 +62,17 @@ struct Ctx {
     PinBuf h_in, h_in2, h_tasks, h_out, h_out2;
     Timing last;
     int ensure(int dev);  // binds the calling thread to `dev` (creates stream/events on first use)
+    // A context dies with its host thread: streams, events, device and pinned staging buffers are given back (a host
+    // application that calls the batch API from short-lived threads must not leak HBM per thread).  On the process's main
+    // thread nothing is destroyed: the process is exiting and the HIP runtime may already be shutting down.
+    ~Ctx();
+    Ctx() = default;
+    Ctx(const Ctx&) = delete;
+    Ctx& operator=(const Ctx&) = delete;
 };
+
+// true on the thread that started the process
+bool on_main_thread();
 
 // timing of the calling thread's most recent batch call (alfa_last_timing)
 extern thread_local Timing g_last_timing;

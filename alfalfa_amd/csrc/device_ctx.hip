@@ -1,6 +1,9 @@
 // device_ctx.hip -- see device_ctx.h
 #include "device_ctx.h"
 
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <map>
 #include <memory>
 
@@ -46,6 +49,26 @@ int device_count() {
     return n;
 }
 
+bool on_main_thread() { return (pid_t)syscall(SYS_gettid) == getpid(); }
+
+Ctx::~Ctx() {
+    if (!stream || on_main_thread()) return;
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
+    (void)hipStreamSynchronize(stream);
+    for (auto& st : side) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : side_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : fill_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : l2_ev) if (e) (void)hipEventDestroy(e);
+    if (fork_ev) (void)hipEventDestroy(fork_ev);
+    for (DevBuf* b : {&d_in, &d_in2, &d_tasks, &d_out, &d_out2, &d_scratch, &d_z, &d_cnt, &d_off, &d_ivl}) b->release();
+    for (PinBuf* b : {&h_in, &h_in2, &h_tasks, &h_out, &h_out2}) b->release();
+    (void)hipStreamDestroy(stream);
+    stream = nullptr;
+}
+
+// The context is usable only when EVERY stream and event exists: a failure part-way tears down what was created, so the
+// next call starts from scratch instead of running on a half-built context.
 int Ctx::ensure(int dev) {
     int n = device_count();
     if (n <= 0) return fail(ALFA_ENODEV, "no HIP device is usable; libalfa_hot has no CPU fallback");
@@ -53,13 +76,26 @@ int Ctx::ensure(int dev) {
     ALFA_HIP(hipSetDevice(dev));
     if (!stream) {
         device = dev;
-        ALFA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        for (auto& e : ev) ALFA_HIP(hipEventCreate(&e));
-        for (auto& st : side) ALFA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        for (auto& e : side_ev) ALFA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto& e : fill_ev) ALFA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto& e : l2_ev) ALFA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ALFA_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        hipStream_t main_stream = nullptr;
+        hipError_t err = hipStreamCreateWithFlags(&main_stream, hipStreamNonBlocking);
+        auto ok = [&](hipError_t e) { if (err == hipSuccess) err = e; return err == hipSuccess; };
+        for (auto& e : ev) if (!ok(hipEventCreate(&e))) break;
+        for (auto& st : side) if (!ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking))) break;
+        for (auto& e : side_ev) if (!ok(hipEventCreateWithFlags(&e, hipEventDisableTiming))) break;
+        for (auto& e : fill_ev) if (!ok(hipEventCreateWithFlags(&e, hipEventDisableTiming))) break;
+        for (auto& e : l2_ev) if (!ok(hipEventCreateWithFlags(&e, hipEventDisableTiming))) break;
+        (void)ok(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        if (err != hipSuccess) {
+            for (auto& st : side) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
+            for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+            for (auto& e : side_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+            for (auto& e : fill_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+            for (auto& e : l2_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+            if (fork_ev) { (void)hipEventDestroy(fork_ev); fork_ev = nullptr; }
+            if (main_stream) (void)hipStreamDestroy(main_stream);
+            return fail(ALFA_EHIP, std::string("creating the context's streams and events: ") + hipGetErrorString(err));
+        }
+        stream = main_stream;          // set last: a context with a stream is complete
     }
     return ALFA_OK;
 }

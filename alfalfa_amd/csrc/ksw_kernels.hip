@@ -1909,9 +1909,17 @@ int run_sync(int mode, const alfa_dp_params* p, const alfa_dp_task* t, int n, vo
     if (n > 0) {
         Ctx* cx;
         if ((rc = current_ctx(&cx))) return rc;
-        thread_local alfa_dp_batch* reuse[3] = {nullptr, nullptr, nullptr};
-        if (!reuse[mode]) reuse[mode] = new alfa_dp_batch();
-        alfa_dp_batch* b = reuse[mode];
+        // recycled from call to call; given back when the thread ends (not on the main thread: the process is exiting)
+        struct Reuse {
+            alfa_dp_batch* b[3] = {nullptr, nullptr, nullptr};
+            ~Reuse() {
+                if (alfa::on_main_thread()) return;
+                for (auto*& x : b) if (x) { (void)hipSetDevice(x->device); release_batch(x); delete x; x = nullptr; }
+            }
+        };
+        thread_local Reuse reuse;
+        if (!reuse.b[mode]) reuse.b[mode] = new alfa_dp_batch();
+        alfa_dp_batch* b = reuse.b[mode];
         const int64_t LIMIT = (int64_t)6 << 30;
         std::vector<int> ids;
         int64_t need = 0;

@@ -41,13 +41,18 @@ alfa_ctx_switch:
 
 namespace alfa {
 
-static thread_local HotSched* tl_sched = nullptr;      // the scheduler whose fibers run on this thread
+static thread_local HotSched* tl_sched = nullptr;
+static constexpr size_t GUARD = 4096;                  // guard page below every fiber stack      // the scheduler whose fibers run on this thread
 
 HotSched::HotSched(const HotOps& ops, const alfa_dp_params& prm, size_t stack_bytes) : ops_(ops), prm_(prm), stack_bytes_(stack_bytes) {}
 
 void HotSched::set_task_log(const std::string& prefix) {
     log_hdr_ = fopen((prefix + ".hdr").c_str(), "wb");
     log_seq_ = fopen((prefix + ".seq").c_str(), "wb");
+    if (!log_hdr_ || !log_seq_) {
+        fprintf(stderr, "ERROR: cannot write the task log %s.{hdr,seq}\n", prefix.c_str());
+        exit(1);
+    }
 }
 
 void HotSched::log_task(int kind, const alfa_dp_task& t) {
@@ -61,14 +66,23 @@ HotSched::~HotSched() {
     if (log_hdr_) fclose(log_hdr_);
     if (log_seq_) fclose(log_seq_);
     for (auto& f : fibers_)
-        if (f.stack) munmap(f.stack, stack_bytes_);
+        if (f.stack) munmap(f.stack - GUARD, stack_bytes_ + GUARD);
 }
 
 void HotSched::fiber_entry() {
     HotSched* self = tl_sched;
     {
         Fiber& f = self->fibers_[self->current_];
-        (*self->job_)(f.job);
+        // an exception cannot unwind past this frame (its return address is a dummy): report it and stop
+        try {
+            (*self->job_)(f.job);
+        } catch (const std::exception& e) {
+            fprintf(stderr, "ERROR: exception while mapping read %d: %s\n", f.job, e.what());
+            exit(1);
+        } catch (...) {
+            fprintf(stderr, "ERROR: unknown exception while mapping read %d\n", f.job);
+            exit(1);
+        }
         f.done = true;
     }
     Fiber& f = self->fibers_[self->current_];
@@ -231,8 +245,11 @@ void HotSched::run(int n, int max_fibers, const std::function<void(int)>& job) {
     const int nf = std::min(n, std::max(1, max_fibers));
     while ((int)fibers_.size() < nf) {
         Fiber f;
-        f.stack = (char*)mmap(nullptr, stack_bytes_, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
-        if (f.stack == (char*)MAP_FAILED) throw std::runtime_error("mmap of a fiber stack failed");
+        // one inaccessible page below every stack: an overflow faults instead of running into the neighbouring fiber
+        char* base = (char*)mmap(nullptr, stack_bytes_ + GUARD, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+        if (base == (char*)MAP_FAILED) throw std::runtime_error("mmap of a fiber stack failed");
+        (void)mprotect(base, GUARD, PROT_NONE);
+        f.stack = base + GUARD;
         fibers_.push_back(f);
     }
     tl_sched = this;

@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <atomic>
 #include <chrono>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -387,7 +388,8 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     const double t_device_ready = since_start();
     FILE* out = fopen(o.outputName.c_str(), "w");
     if (!out) { fprintf(stderr, "ERROR: cannot write %s\n", o.outputName.c_str()); return 1; }
-    fputs(sam_header(idx, argc, argv).c_str(), out);
+    std::atomic<bool> write_failed{false};
+    if (fputs(sam_header(idx, argc, argv).c_str(), out) < 0) write_failed = true;
 
     std::vector<std::unique_ptr<HotSched>> scheds((size_t)T);
     std::vector<std::unique_ptr<Mapper>> mappers((size_t)T);
@@ -438,7 +440,8 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
             BatchP bp;
             while (mapped.pop(bp)) {
                 double t0 = now();
-                for (const std::string& s : bp->text) fwrite(s.data(), 1, s.size(), out);
+                for (const std::string& s : bp->text)
+                    if (fwrite(s.data(), 1, s.size(), out) != s.size()) write_failed = true;
                 spare.push(std::move(bp));
                 t_print += now() - t0;
             }
@@ -568,7 +571,8 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         printf("sequences read: %ld\nsequences mapped (mate1): %ld\nsequences mapped (mate2): %ld\n"
                "alignments printed (mate1): %ld\nalignments printed (mate2): %ld\n", total, mapped1, mapped2, printed1, printed2);
     }
-    fclose(out);
+    if (fclose(out) != 0) write_failed = true;
+    if (write_failed) { fprintf(stderr, "ERROR: writing %s failed (disk full?)\n", o.outputName.c_str()); return 1; }
     if (o.stats) {
         SchedStats s;
         for (auto& sc : scheds) {

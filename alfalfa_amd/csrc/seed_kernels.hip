@@ -1821,6 +1821,21 @@ void plan_release(alfa_seed_plan* pl) {
     if (pl->ev0) { (void)hipEventDestroy(pl->ev0); (void)hipEventDestroy(pl->ev1); pl->ev0 = pl->ev1 = nullptr; }
 }
 
+// the calling thread's recycled plans (slot 0: alfa_seed_batch, 1: alfa_seed_regions_batch); given back when the thread
+// ends (not on the main thread: the process is exiting)
+alfa_seed_plan* thread_plan(int slot) {
+    struct Reuse {
+        alfa_seed_plan* p[2] = {nullptr, nullptr};
+        ~Reuse() {
+            if (alfa::on_main_thread()) return;
+            for (auto*& x : p) if (x) { if (x->ix) (void)hipSetDevice(x->ix->device); plan_release(x); delete x; x = nullptr; }
+        }
+    };
+    thread_local Reuse reuse;
+    if (!reuse.p[slot]) reuse.p[slot] = new alfa_seed_plan();
+    return reuse.p[slot];
+}
+
 }  // namespace
 
 extern "C" {
@@ -1869,8 +1884,7 @@ int alfa_seed_batch(alfa_index* ix, int mem_type, const alfa_seed_query* q, int 
     if (!ix || !matches || !offsets || nq < 0 || (nq > 0 && !q)) return alfa::fail(ALFA_EINVAL, "null argument");
     alfa::Ctx* cx = alfa::thread_ctx(ix->device);
     if (!cx) return ALFA_ENODEV;
-    thread_local alfa_seed_plan* reuse = nullptr;   // buffers are recycled from call to call
-    if (!reuse) reuse = new alfa_seed_plan();
+    alfa_seed_plan* reuse = thread_plan(0);         // buffers are recycled from call to call
     int rc;
     if ((rc = plan_fill(reuse, cx, ix, mem_type, q, nq)) || (rc = plan_launch(reuse, cx)) || (rc = plan_fetch(reuse, cx, matches, offsets))) return rc;
     alfa::g_last_timing.kernel_ms = alfa_seed_plan_kernel_ms(reuse);
@@ -1889,9 +1903,7 @@ int alfa_seed_regions_batch(alfa_index* ix, int mem_type, const alfa_seed_query*
         return alfa::fail(ALFA_EINVAL, "null argument");
     alfa::Ctx* cx = alfa::thread_ctx(ix->device);
     if (!cx) return ALFA_ENODEV;
-    thread_local alfa_seed_plan* reuse = nullptr;
-    if (!reuse) reuse = new alfa_seed_plan();
-    alfa_seed_plan* pl = reuse;
+    alfa_seed_plan* pl = thread_plan(1);
     int rc;
     *matches = nullptr; *regions = nullptr; *members = nullptr;
     if ((rc = plan_fill(pl, cx, ix, mem_type, q, nq)) || (rc = plan_launch(pl, cx)) || (rc = plan_fetch(pl, cx, matches, match_off))) return rc;

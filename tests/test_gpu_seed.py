@@ -239,3 +239,45 @@ def test_resident_objects_belong_to_their_thread(gpu):
     assert np.array_equal(batch.fetch(), np.full(8, 40, np.int32))
     mo, oo = O.orc_seed_batch(hidx.view, ffi.SEED_SMAM, ffi.make_seed_queries(reads, 30, 1000, 1))
     assert np.array_equal(m, mo)
+
+
+def test_short_lived_threads_give_their_memory_back(gpu):
+    """a host thread's context (streams, staging buffers, recycled plan and batches) dies with the thread: calling the batch
+    API from many short-lived threads must not accumulate HBM"""
+    import ctypes as C
+    import threading
+    import hip_rt
+    import seqgen
+    rng = np.random.default_rng(10)
+    ref = seqgen.rand_ref(rng, 200000)
+    hidx = ffi.HostIndex.build_mem(["x"], [ref], K=12)
+    didx = ffi.DeviceIndex(hidx, 0)
+    reads = seqgen.sim_reads(rng, ref, 3000, 200, 300, 0.02)
+    q = ffi.make_seed_queries(reads, 30, 1000, 1)
+    P = ffi.default_params()
+    a = rng.integers(0, 4, 300).astype(np.uint8)
+    tasks, keep = ffi.make_dp_tasks([(a, a.copy())] * 20000, 20, 0)
+    r = hip_rt.rt()
+    r.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert r.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    def work():
+        didx.seed_batch(ffi.SEED_SMAM, q)
+        ffi.ksw_nw_batch(P, tasks)
+        ffi.ksw_global_batch(P, tasks)
+
+    def once():
+        t = threading.Thread(target=work)
+        t.start()
+        t.join()
+    once()
+    once()
+    before = free_bytes()
+    for _ in range(6):
+        once()
+    after = free_bytes()
+    assert before - after < (8 << 20), (before, after)      # each thread used ~100 MB while it lived
