@@ -1544,11 +1544,9 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
         if (bc[k]) {
             const size_t lds = (size_t)(QCAP[k] + 2) * 64 * sizeof(int2) + (size_t)(QCAP[k] + 1) * 64;
             if (lds > 48 * 1024) {
-                static bool raised[64] = {false};
-                if (!raised[b->device & 63]) {
+                static std::atomic<bool> raised[64];
+                if (!raised[b->device & 63].exchange(true))
                     (void)hipFuncSetAttribute((const void*)ksw_lane_kernel<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                    raised[b->device & 63] = true;
-                }
             }
             hipLaunchKernelGGL((ksw_lane_kernel<MODE, true>), dim3((bc[k] + 63) / 64), dim3(64), lds, st, d_t + o, bc[k], d_seq, d_prm, d_out,
                                (int2*)nullptr, d_z, d_cig, d_ncig, QCAP[k]);

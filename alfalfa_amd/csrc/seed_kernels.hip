@@ -31,6 +31,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -1679,13 +1680,14 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
     if (pl->suflink && (rc = pl->d_scr.reserve(4 * (size_t)nq * (size_t)ix->K + 64))) return rc;
     pl->nseg = 1;
     if (pl->persistent) {
-        static int n_cu[64] = {0};
-        int& ncu = n_cu[ix->device & 63];
+        static std::atomic<int> n_cu[64];          // several worker threads may get here at once: the set-up is idempotent
+        int ncu = n_cu[ix->device & 63].load();
         if (!ncu) {
             hipDeviceProp_t prop;
             ALFA_HIP(hipGetDeviceProperties(&prop, ix->device));
             ALFA_HIP(hipFuncSetAttribute((const void*)smam_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
             ncu = std::max(1, prop.multiProcessorCount);
+            n_cu[ix->device & 63].store(ncu);
         }
         pl->nseg = std::max(1, std::min(ncu, (nq + PWAVES - 1) / PWAVES));
         const int room = ((160 * 1024 - KBIT_BYTES - 1024) / PWAVES - WQ_BYTES) / 2;      // LDS bytes a wave can have for its read (x2: codes)
