@@ -40,6 +40,18 @@ def test_text_positions_beyond_2_31(gpu):
     refb = ref.tobytes()
     del ref
     hidx = ffi.HostIndex.build_mem(["chr1"], [refb], K=K_TEXT)
+    # the same index built on the GPU (index_build.hip): every array equal, with suffix positions beyond 2^31
+    ffi.index_build_on_device(0)
+    try:
+        dev_built = ffi.HostIndex.build_mem(["chr1"], [refb], K=K_TEXT)
+    finally:
+        ffi.index_build_on_device(-1)
+    a, b = hidx.arrays(), dev_built.arrays()
+    for k in a:
+        if isinstance(a[k], np.ndarray):
+            assert np.array_equal(a[k], b[k]), k
+    assert int(np.asarray(a["SA"]).max()) > (1 << 31)
+    del dev_built, a, b
     del refb
     assert hidx.view.N > (1 << 31) and hidx.view.n == hidx.view.N // K_TEXT
     didx = ffi.DeviceIndex(hidx, 0)
