@@ -1470,7 +1470,10 @@ int lane2_class(int mode, const alfa_dp_params* p, const alfa_dp_task& x, int w,
     static const int64_t latcap_env = getenv("ALFA_DP_LATCAP") ? atoll(getenv("ALFA_DP_LATCAP")) : 0;
     static const int64_t latcap_mode[3] = {16000, 16000, 24000};       // measured on the C3 stream (tools/dp_replay.py sweeps)
     const int64_t latcap = latcap_env ? latcap_env : latcap_mode[mode];
-    static const size_t ldscap = getenv("ALFA_DP_LDSCAP") ? (size_t)atoll(getenv("ALFA_DP_LDSCAP")) : 24 * 1024;
+    // ksw_global: 32 KiB keeps the C3 stream's longest gap fills in the common launch (a second launch for a handful of
+    // tasks costs a cross-stream fork/join, ~25 us: 0.137 -> 0.112 ms per batch)
+    static const size_t ldscap_env = getenv("ALFA_DP_LDSCAP") ? (size_t)atoll(getenv("ALFA_DP_LDSCAP")) : 0;
+    const size_t ldscap = ldscap_env ? ldscap_env : (mode == MODE_GLOBAL ? 32 * 1024 : 24 * 1024);
     if (off || p->m > QPAD || x.qlen < 1 || rows < 1) return -1;
     const int W = 2 * w + 1;
     if (W > 64) return -1;
