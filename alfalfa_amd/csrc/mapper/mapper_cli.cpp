@@ -12,12 +12,14 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include "../seqio.h"
 
@@ -156,13 +158,13 @@ bool next_read(SeqReader& rd, Read& r) {
 }
 
 // ---- parallel FASTQ parse (fastqInputReader::nextRead src/fasta.cpp:135-159 + src/main.cpp:64-92)
-// The reader thread of a plain (not gzip) file only SPLITS records: four memchr calls per record over the memory-mapped
-// file.  Everything the reference's reader does per record -- name up to the first white space, lower-casing, '/1' '/2'
+// The reader thread only SPLITS records: four memchr calls per record over the memory-mapped file, or -- gzip input -- over
+// the chunk it has just inflated.  Everything the reference's reader does per record -- name up to the first white space, lower-casing, '/1' '/2'
 // stripping, the strings themselves -- happens on the worker that maps the read (materialize()).  The split takes the fast
 // path only for records it can prove kseq would parse the same way: four lines, '@' first, a non-empty sequence line that
 // does not start with '>', '+' or '@', '+' on the third, a quality line exactly as long as the sequence and no '\r' anywhere.
 // The first record that fails a check sends the rest of the file through SeqReader (the kseq restatement), on the reader
-// thread as before; gzip input always takes that path.
+// thread as before.
 struct RawRec {
     const char* p = nullptr;      // '@' of the record; nullptr: the Read was filled by the general parser
     uint32_t l1 = 0, l2 = 0;      // lengths of the header line (with '@') and of the sequence (= quality) line
@@ -171,7 +173,12 @@ struct RawRec {
 
 class ReadSource {
    public:
-    ~ReadSource() { if (map_ && map_ != MAP_FAILED) munmap((void*)map_, size_); if (fd_ >= 0) ::close(fd_); }
+    typedef std::shared_ptr<std::vector<char>> Chunk;
+    ~ReadSource() {
+        if (map_ && map_ != MAP_FAILED) munmap((void*)map_, size_);
+        if (fd_ >= 0) ::close(fd_);
+        if (gz_) gzclose(gz_);
+    }
     bool open(const char* path) {
         static const bool no_fast = getenv("ALFA_NO_FAST_FASTQ") != nullptr;
         fd_ = ::open(path, O_RDONLY);
@@ -182,29 +189,67 @@ class ReadSource {
             if (map_ != MAP_FAILED && !((unsigned char)map_[0] == 0x1f && (unsigned char)map_[1] == 0x8b)) {
                 (void)madvise((void*)map_, size_, MADV_SEQUENTIAL);
                 fast_ = true;
+                base_ = map_; end_ = size_; final_ = true;
                 return true;
             }
+            const bool gz = map_ != MAP_FAILED;
             if (map_ != MAP_FAILED) munmap((void*)map_, size_);
             map_ = nullptr;
+            if (gz) {
+                // gzip: this thread inflates into chunks and splits them; the workers still build the reads.  A chunk stays
+                // alive as long as a batch holds records in it (chunk()).
+                gz_ = gzopen(path, "r");
+                if (gz_) {
+                    (void)gzbuffer(gz_, 1 << 20);
+                    fast_ = true; chunked_ = true;
+                    base_ = nullptr; end_ = 0; pos_ = 0; final_ = false;
+                    return true;
+                }
+            }
         }
         return slow_.open(path);
     }
+    // the memory the last record returned by next() lies in (gzip input); null for a memory-mapped file
+    const Chunk& chunk() const { return cur_; }
     // 0: end of input; 1: x describes a record (r untouched); 2: r filled by the general parser (x.p == nullptr)
     int next(Read& r, RawRec& x) {
-        if (fast_) {
-            if (pos_ >= size_) return 0;
-            if (split(x)) return 1;
+        while (fast_) {
+            if (pos_ >= end_ && final_) return 0;
+            if (pos_ < end_ && split(x)) return 1;
+            if (chunked_ && !final_) { refill(false); continue; }       // the record may simply be cut off: more input first
             // not provably kseq-equivalent from here on: the general parser takes over at this byte
+            if (chunked_) refill(true);
             fast_ = false;
-            slow_.open_mem(map_ + pos_, size_ - pos_);
+            slow_.open_mem(base_ + pos_, end_ - pos_);
         }
         x.p = nullptr;
         return next_read(slow_, r) ? 2 : 0;
     }
    private:
+    // a new chunk: the unconsumed tail of the current one, then inflated input until the chunk is full (all: until the end)
+    void refill(bool all) {
+        const size_t tail = end_ - pos_;
+        size_t cap = std::max<size_t>(CHUNK, 2 * tail + (1 << 16));
+        Chunk nc = std::make_shared<std::vector<char>>();
+        nc->resize(cap);
+        if (tail) memcpy(nc->data(), base_ + pos_, tail);
+        size_t have = tail;
+        for (;;) {
+            if (have == cap) {
+                if (!all) break;
+                cap *= 2;
+                nc->resize(cap);
+            }
+            const int got = gzread(gz_, nc->data() + have, (unsigned)std::min<size_t>(cap - have, 1u << 30));
+            if (got <= 0) { final_ = true; break; }
+            have += (size_t)got;
+        }
+        cur_ = nc;
+        base_ = cur_->data(); end_ = have; pos_ = 0;
+    }
     bool split(RawRec& x) {
-        const char* b = map_ + pos_;
-        const char* e = map_ + size_;
+        const char* b = base_ + pos_;
+        const char* e = base_ + end_;
         if (*b != '@') return false;
         const char* n1 = (const char*)memchr(b, '\n', (size_t)(e - b));
         if (!n1) return false;
@@ -220,17 +265,23 @@ class ReadSource {
         if ((size_t)(e - s4) < l2) return false;
         const char* n4 = s4 + l2;                       // the quality line must end exactly here
         if (n4 < e && *n4 != '\n') return false;
+        if (n4 == e && !final_) return false;           // ... which only the end of the INPUT settles, not the end of a chunk
         if (memchr(s4, '\n', l2)) return false;         // ... and not before
         const size_t reclen = (size_t)(n4 - b);
         if (memchr(b, '\r', reclen) || reclen >= (1ull << 31)) return false;
         x.p = b; x.l1 = (uint32_t)(n1 - b); x.l2 = (uint32_t)l2; x.o2 = (uint32_t)(s2 - b); x.o4 = (uint32_t)(s4 - b);
-        pos_ = (size_t)(n4 - map_) + (n4 < e ? 1 : 0);
+        pos_ = (size_t)(n4 - base_) + (n4 < e ? 1 : 0);
         return true;
     }
+    static constexpr size_t CHUNK = 32u << 20;
     int fd_ = -1;
     const char* map_ = nullptr;
-    size_t size_ = 0, pos_ = 0;
-    bool fast_ = false;
+    size_t size_ = 0;
+    const char* base_ = nullptr;      // the bytes being split: the mapping, or the current chunk
+    size_t end_ = 0, pos_ = 0;
+    bool fast_ = false, chunked_ = false, final_ = false;
+    gzFile gz_ = nullptr;
+    Chunk cur_;
     SeqReader slow_;
 };
 
@@ -409,6 +460,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     struct Batch {
         std::vector<Read> a, b;               // b stays empty for single-end input; objects beyond n are spares of earlier batches
         std::vector<RawRec> ra, rb;           // records the reader thread only split: the workers materialise them
+        std::vector<ReadSource::Chunk> keep;  // gzip input: the inflated chunks those records lie in
         int n = 0;                            // reads (pairs) of this batch
         std::vector<std::string> text;        // rendered SAM, one chunk per worker slice, in input order
         std::vector<long> cnt;                // per slice: mapped1, printed1, mapped2, printed2
@@ -429,6 +481,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 BatchP bp;
                 if (!spare.try_pop(bp)) bp.reset(new Batch);
                 bp->n = 0;
+                bp->keep.clear();
                 bool ok = fill(*bp);
                 t_parse += now() - t0;
                 if (!ok) break;
@@ -476,6 +529,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                     if ((int)B.a.size() <= B.n) { B.a.emplace_back(); B.ra.emplace_back(); }
                     Read& r = B.a[B.n];
                     const int got = rd.next(r, B.ra[B.n]);
+                    if (got == 1 && rd.chunk() && (B.keep.empty() || B.keep.back() != rd.chunk())) B.keep.push_back(rd.chunk());
                     if (!got) break;
                     cur += got == 1 ? (int64_t)B.ra[B.n].l2 : (int64_t)r.sequence.length();
                     B.n++;
@@ -520,6 +574,8 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                     Read& b = B.b[B.n];
                     const int ok1 = r1.next(a, B.ra[B.n]);
                     const int ok2 = r2.next(b, B.rb[B.n]);     // the reference keeps only the second status (src/main.cpp:157-158)
+                    for (ReadSource* rs : {&r1, &r2})
+                        if (rs->chunk() && std::find(B.keep.begin(), B.keep.end(), rs->chunk()) == B.keep.end()) B.keep.push_back(rs->chunk());
                     if (!ok1) {
                         // mate file 1 ended first: the reference's reader leaves its read object as it was.  The object may be a
                         // spare of an earlier batch here, so give it the state a fresh read_t has

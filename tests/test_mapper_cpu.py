@@ -53,7 +53,8 @@ def test_host_mapper_c5_paired_long_reads():
 @pytest.mark.skipif(not os.path.exists(M.CPU_EXE), reason="tests/_cpu_mapper not built")
 def test_parallel_fastq_parse_equals_general_parser():
     """the reader thread only splits plain 4-line FASTQ records (workers build the reads); anything else -- CRLF,
-    multi-line records, FASTA, gzip, a missing final newline, junk between records -- goes through the kseq restatement.
+    multi-line records, FASTA, junk between records -- goes through the kseq restatement; gzip input is inflated chunk by chunk on
+    the reader thread and split the same way.
     Same SAM either way, and the same as with the fast path switched off."""
     import gzip
     import subprocess
@@ -92,9 +93,19 @@ def test_parallel_fastq_parse_equals_general_parser():
         assert a == b, name
         assert a.count(b"\n") >= 40, name
         bodies[name] = a
-    with gzip.open(os.path.join(d, "pp_plain.fq.gz"), "wt") as f:
-        f.write(variants["plain"])
-    assert run(os.path.join(d, "pp_plain.fq.gz"), True) == bodies["plain"]
+    # gzip: the reader inflates chunk by chunk and splits the chunks (records cut by a chunk end, the general parser taking
+    # over in the middle of a chunk, a file larger than one chunk)
+    for name in ("plain", "no_final_newline", "crlf_from_10", "multiline_from_5", "fasta"):
+        with gzip.open(os.path.join(d, "pp_%s.fq.gz" % name), "wt", newline="") as f:
+            f.write(variants[name])
+        assert run(os.path.join(d, "pp_%s.fq.gz" % name), True) == bodies[name], name
+    big = variants["plain"] * 3000                                      # ~40 MB: more than one 32 MiB chunk
+    with gzip.open(os.path.join(d, "pp_big.fq.gz"), "wt", compresslevel=1) as f:
+        f.write(big)
+    assert len(big) > (33 << 20)
+    a, b = run(os.path.join(d, "pp_big.fq.gz"), True), run(os.path.join(d, "pp_big.fq.gz"), False)
+    assert a == b and a.count(b"\n") >= 40 * 3000
+    os.remove(os.path.join(d, "pp_big.fq.gz"))
     assert bodies["no_final_newline"] == bodies["plain"] == bodies["junk_between"]
 
 
