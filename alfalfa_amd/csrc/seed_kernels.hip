@@ -1564,6 +1564,7 @@ int alfa_index_device(const alfa_index* ix) { return ix ? ix->device : -1; }
 
 struct alfa_seed_plan {
     alfa_index* ix = nullptr;
+    int dev = 0;                 // ix->device, kept for the release of a recycled plan
     int nq = 0, max_plen = 0;
     int64_t total_pref = 0;
     size_t read_bytes = 0;
@@ -1603,7 +1604,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
     if (!ix->has_child && smem_like)
         return alfa::fail(ALFA_ENOTSUP, "SMEM / SMEMP need an index with a child table (the reference calls traverse_faster unconditionally)");
 
-    pl->ix = ix; pl->nq = nq; pl->launched = false; pl->mem_type = mem_type;
+    pl->ix = ix; pl->dev = ix->device; pl->nq = nq; pl->launched = false; pl->mem_type = mem_type;
     pl->work_rec = mem_type == ALFA_SEED_SMAM ? sizeof(WorkRec) : sizeof(WorkRec2);
     if (!pl->ev0) { ALFA_HIP(hipEventCreate(&pl->ev0)); ALFA_HIP(hipEventCreate(&pl->ev1)); }
     size_t bytes = 0;
@@ -1823,14 +1824,18 @@ void plan_release(alfa_seed_plan* pl) {
     if (pl->ev0) { (void)hipEventDestroy(pl->ev0); (void)hipEventDestroy(pl->ev1); pl->ev0 = pl->ev1 = nullptr; }
 }
 
-// the calling thread's recycled plans (slot 0: alfa_seed_batch, 1: alfa_seed_regions_batch); given back when the thread
-// ends (not on the main thread: the process is exiting)
+// the calling thread's recycled plans (slot 0: alfa_seed_batch, 1: alfa_seed_regions_batch); buried when the thread ends
+// (device_ctx.h: a live thread releases them)
 alfa_seed_plan* thread_plan(int slot) {
     struct Reuse {
         alfa_seed_plan* p[2] = {nullptr, nullptr};
         ~Reuse() {
-            if (alfa::on_main_thread()) return;
-            for (auto*& x : p) if (x) { if (x->ix) (void)hipSetDevice(x->ix->device); plan_release(x); delete x; x = nullptr; }
+            for (auto*& x : p)
+                if (x) {
+                    x->ix = nullptr;          // the index may be freed before the plan is released
+                    alfa::bury([](void* q) { alfa_seed_plan* d = (alfa_seed_plan*)q; (void)hipSetDevice(d->dev); plan_release(d); delete d; }, x);
+                    x = nullptr;
+                }
         }
     };
     thread_local Reuse reuse;

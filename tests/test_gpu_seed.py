@@ -276,8 +276,10 @@ def test_short_lived_threads_give_their_memory_back(gpu):
         t.join()
     once()
     once()
+    ffi.sync(0)
     before = free_bytes()
     for _ in range(6):
         once()
+    ffi.sync(0)                 # any library call on a live thread releases what the finished threads left behind
     after = free_bytes()
     assert before - after < (8 << 20), (before, after)      # each thread used ~100 MB while it lived
