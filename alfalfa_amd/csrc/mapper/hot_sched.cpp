@@ -136,7 +136,8 @@ void HotSched::flush() {
             if (rc) die(ops_, "alfa_seed_batch", rc);
             for (size_t k = 0; k < who.size(); ++k) {
                 std::vector<Match>* out = seed_[who[k]].out;
-                for (int64_t j = off[k]; j < off[k + 1]; ++j) out->push_back(Match{m[j].ref, m[j].query, m[j].len});
+                static_assert(sizeof(Match) == sizeof(alfa_match), "Match == alfa_match");
+                out->insert(out->end(), (const Match*)(m + off[k]), (const Match*)(m + off[k + 1]));
             }
             ops_.free_fn(m);
             stats_.seed_calls++;
