@@ -44,6 +44,7 @@ struct alfa_index {
     int64_t N = 0, n = 0, K = 1, logN = 0, NKm1 = 0, nM = 0;
     int has_child = 0, has_suflink = 0, has_kmer = 0;
     uint8_t nul_sub = 0;     // a byte value that occurs nowhere in S (and is not 0): what a NUL inside a read is packed as
+    double kbit_fill = 0;    // fraction of the 10-mers that have a sampled suffix: near 1 the presence bitmap filters nothing
     alfa::DevBuf S, SA, LCP, Midx, Mval, CHILD, KMR, KMR2, KBIT, ISA;
 };
 
@@ -148,6 +149,13 @@ struct PatD {           // read staged in LDS; out-of-range reads give '\0' like
     __device__ __forceinline__ uint32_t at(int i) const { return (i >= 0 && i < len) ? p[i] : 0u; }
     __device__ __forceinline__ uint64_t load8(int i) const { return ld8(p + i); }   // caller keeps i in [-8, len+8]
 };
+struct PatG {   // read bytes straight from global memory (kernel B touches only a few of them)
+    const uint8_t* p;
+    int len;
+    __device__ __forceinline__ uint32_t at(int i) const { return (i >= 0 && i < len) ? p[i] : 0u; }
+    __device__ __forceinline__ uint64_t load8(int i) const { return ld8(p + i); }
+};
+
 
 // number of leading positions t < L with S[spos+t] == P[c+t]; needs spos+L <= N+16 and c+L <= |P|
 template <class PAT>
@@ -541,6 +549,93 @@ __device__ __forceinline__ int wave_excl_scan(int v, int& total) {
 struct Q3 { int32_t read, prefix, start, end; uint32_t z, w; };     // prefix bit 31: query without 10-mer jump (|P| < 10)
 constexpr int Q3_CAP = 128;
 
+// Evaluation of one survivor of the table stage (stage 3 of smam_count_kernel; the whole per-query work of the sorted path):
+// the deepest match of P[prefix..] inside [start,end] and how many matches it emits.  ent.prefix bit 31: no 10-mer jump.
+__device__ __forceinline__ void eval_entry(const DIdx& X, const SeedQ& Q, const uint8_t* __restrict__ reads, const int K, const Q3& ent, int& cnt,
+                                           int& start, int& end, int& depth) {
+    cnt = 0; start = ent.start; end = ent.end; depth = 0;
+    const int prefix = ent.prefix & 0x7fffffff;
+    PatD P;
+    P.len = Q.plen;
+    P.p = reads + Q.poff;                               // the read's LDS copy may be gone: global bytes
+    const int step = Q.sparse_q * K;
+    const int min_lenK = Q.min_len - (step - 1);
+    const int minMin_len = Q.sparse_q > 1 ? Q.min_len - K : Q.min_len;
+    const int maxCount = Q.sparse_q * Q.max_count;
+    // Hits with 1..4 sampled suffixes behind the 10-mer (all but a fraction of a percent on a non-repetitive
+    // reference) are evaluated directly.  The child-table descent reaches, by construction, the deepest match M of
+    // P[prefix..] among the suffixes of the interval and ends on the sub-interval of the suffixes that attain it (at a
+    // branching node when no child continues P, inside an edge on a mismatch, or at the end of the read or text):
+    // with so few suffixes, M follows from comparing each of them with the read, all text chunks being independent
+    // loads (16 bytes per suffix and round trip) instead of ~10 dependent CHILD/LCP/SA/S probes.  A single suffix
+    // is the run of comparisons of :758,:781-786.
+    int64_t sas[4] = {0, 0, 0, 0};
+    int lim[4] = {-1, -1, -1, -1}, mi[4] = {-1, -1, -1, -1};     // -1: unused slot
+    bool go[4] = {false, false, false, false};
+    bool direct = false;
+    const int c0 = prefix + KMER;
+    if (ent.prefix >= 0) {
+        depth = KMER;
+        const int nsuf = end - start + 1;
+        if (nsuf >= 1 && nsuf <= 4) {
+            direct = true;
+            sas[0] = (int64_t)ent.z;
+            if (nsuf >= 2) sas[1] = (int64_t)ent.w;
+            if (nsuf >= 3) sas[2] = (int64_t)X.SA[start + 2];
+            if (nsuf >= 4) sas[3] = (int64_t)X.SA[start + 3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nsuf) {
+                    lim[k] = (int)max((int64_t)0, min((int64_t)(Q.plen - c0), X.N - (sas[k] + KMER)));
+                    mi[k] = 0;
+                    go[k] = lim[k] > 0;
+                }
+        }
+    }
+    if (direct) {
+        for (int off = 0; go[0] || go[1] || go[2] || go[3]; off += 16) {
+            uint64_t a0[4], a1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (go[k]) { a0[k] = ld8(X.S + sas[k] + KMER + off); a1[k] = ld8(X.S + sas[k] + KMER + off + 8); }
+            const uint64_t b0 = P.load8(c0 + off), b1 = P.load8(c0 + off + 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (go[k]) {
+                    const uint64_t x0 = a0[k] ^ b0, x1 = a1[k] ^ b1;
+                    int m = 16;
+                    if (x0) m = __builtin_ctzll(x0) >> 3;
+                    else if (x1) m = 8 + (__builtin_ctzll(x1) >> 3);
+                    if (!(m >= 16 && lim[k] > off + 16)) { mi[k] = min(off + m, lim[k]); go[k] = false; }
+                }
+        }
+        const int M = max(max(mi[0], mi[1]), max(mi[2], mi[3]));
+        int ns = 3, ne = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) if (mi[k] == M) ns = k;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (mi[k] == M) ne = k;
+        depth = KMER + M;
+        end = start + ne; start = start + ns;
+        // keep the SA values of the surviving suffixes addressable by (rank - start)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (ns > k) { sas[0] = sas[1]; sas[1] = sas[2]; sas[2] = sas[3]; }
+    } else {
+        traverse_from(X, P, prefix, start, end, depth, Q.plen, -1);
+    }
+    if (depth > 1 && depth >= min_lenK && (end - start + 1) <= maxCount) {
+        int64_t mr; int mq, ml;
+        if (direct) {
+            for (int k = 0; k <= end - start; ++k) {
+                const int64_t sk = k == 0 ? sas[0] : k == 1 ? sas[1] : k == 2 ? sas[2] : sas[3];
+                cnt += lmax_strict(X, P, prefix, sk, depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
+            }
+        } else
+            for (int i = start; i <= end; ++i)
+                cnt += lmax_strict(X, P, prefix, (int64_t)X.SA[i], depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
+    }
+}
+
 __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
                                                            unsigned long long* __restrict__ read_total, WorkRec* __restrict__ work,
                                                            int* __restrict__ seg_count, int seg_cap, int nq, int lds_stride,
@@ -583,85 +678,7 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
         const int prefix = ent.prefix & 0x7fffffff;
         if (have) {
             const SeedQ Q = qs[ent.read];
-            PatD P;
-            P.len = Q.plen;
-            P.p = reads + Q.poff;                               // the read's LDS copy may be gone: global bytes
-            const int step = Q.sparse_q * K;
-            const int min_lenK = Q.min_len - (step - 1);
-            const int minMin_len = Q.sparse_q > 1 ? Q.min_len - K : Q.min_len;
-            const int maxCount = Q.sparse_q * Q.max_count;
-            // Hits with 1..4 sampled suffixes behind the 10-mer (all but a fraction of a percent on a non-repetitive
-            // reference) are evaluated directly.  The child-table descent reaches, by construction, the deepest match M of
-            // P[prefix..] among the suffixes of the interval and ends on the sub-interval of the suffixes that attain it (at a
-            // branching node when no child continues P, inside an edge on a mismatch, or at the end of the read or text):
-            // with so few suffixes, M follows from comparing each of them with the read, all text chunks being independent
-            // loads (16 bytes per suffix and round trip) instead of ~10 dependent CHILD/LCP/SA/S probes.  A single suffix
-            // is the run of comparisons of :758,:781-786.
-            int64_t sas[4] = {0, 0, 0, 0};
-            int lim[4] = {-1, -1, -1, -1}, mi[4] = {-1, -1, -1, -1};     // -1: unused slot
-            bool go[4] = {false, false, false, false};
-            bool direct = false;
-            const int c0 = prefix + KMER;
-            if (ent.prefix >= 0) {
-                depth = KMER;
-                const int nsuf = end - start + 1;
-                if (nsuf >= 1 && nsuf <= 4) {
-                    direct = true;
-                    sas[0] = (int64_t)ent.z;
-                    if (nsuf >= 2) sas[1] = (int64_t)ent.w;
-                    if (nsuf >= 3) sas[2] = (int64_t)X.SA[start + 2];
-                    if (nsuf >= 4) sas[3] = (int64_t)X.SA[start + 3];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k < nsuf) {
-                            lim[k] = (int)max((int64_t)0, min((int64_t)(Q.plen - c0), X.N - (sas[k] + KMER)));
-                            mi[k] = 0;
-                            go[k] = lim[k] > 0;
-                        }
-                }
-            }
-            if (direct) {
-                for (int off = 0; go[0] || go[1] || go[2] || go[3]; off += 16) {
-                    uint64_t a0[4], a1[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (go[k]) { a0[k] = ld8(X.S + sas[k] + KMER + off); a1[k] = ld8(X.S + sas[k] + KMER + off + 8); }
-                    const uint64_t b0 = P.load8(c0 + off), b1 = P.load8(c0 + off + 8);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (go[k]) {
-                            const uint64_t x0 = a0[k] ^ b0, x1 = a1[k] ^ b1;
-                            int m = 16;
-                            if (x0) m = __builtin_ctzll(x0) >> 3;
-                            else if (x1) m = 8 + (__builtin_ctzll(x1) >> 3);
-                            if (!(m >= 16 && lim[k] > off + 16)) { mi[k] = min(off + m, lim[k]); go[k] = false; }
-                        }
-                }
-                const int M = max(max(mi[0], mi[1]), max(mi[2], mi[3]));
-                int ns = 3, ne = 0;
-#pragma unroll
-                for (int k = 3; k >= 0; --k) if (mi[k] == M) ns = k;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (mi[k] == M) ne = k;
-                depth = KMER + M;
-                end = start + ne; start = start + ns;
-                // keep the SA values of the surviving suffixes addressable by (rank - start)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) if (ns > k) { sas[0] = sas[1]; sas[1] = sas[2]; sas[2] = sas[3]; }
-            } else {
-                traverse_from(X, P, prefix, start, end, depth, Q.plen, -1);
-            }
-            if (depth > 1 && depth >= min_lenK && (end - start + 1) <= maxCount) {
-                int64_t mr; int mq, ml;
-                if (direct) {
-                    for (int k = 0; k <= end - start; ++k) {
-                        const int64_t sk = k == 0 ? sas[0] : k == 1 ? sas[1] : k == 2 ? sas[2] : sas[3];
-                        cnt += lmax_strict(X, P, prefix, sk, depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
-                    }
-                } else
-                    for (int i = start; i <= end; ++i)
-                        cnt += lmax_strict(X, P, prefix, (int64_t)X.SA[i], depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
-            }
+            eval_entry(X, Q, reads, K, ent, cnt, start, end, depth);
         }
         // offsets: an exclusive scan over the wave, made relative to the first entry of the same read, plus what earlier
         // evaluations already handed out inside that read
@@ -815,6 +832,110 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
     if (threadIdx.x == 0) seg_count[blockIdx.x] = sh_wcount;
 }
 
+// ---------------------------------------------------------------- kernel A, sorted form: indexes beyond the caches
+// On an index that does not fit L2 / Infinity Cache (C4: 175 MB, every 10-mer holds ~8 suffixes) every probe of the table, of
+// SA / LCP / CHILD and of the text costs a whole 64-byte sector: the persistent kernel moves 13x its algorithmic bytes and is
+// bound by memory transactions (profiles/r02_c4_pmc_*).  The queries of a batch are independent, so they are evaluated in
+// 10-MER ORDER instead: the ~12 queries of a batch that share a 10-mer (and their neighbours in the table) then touch the
+// same sectors at the same time.  Emission order is restored for free: every query writes its count at its FLAT index
+// (read-major, then the reference's prefix order), one exclusive scan over that array yields the offsets of all matches.
+//   sorted_keys_kernel   (read, t) -> key = 10-mer code (TABLE: no table jump; TABLE+1: emits nothing), value = read << 32 | t
+//   hipCUB radix sort    21 key bits
+//   sorted_eval_kernel   one lane per sorted query: table entry, eval_entry (direct evaluation / child-table descent), count
+//   hipCUB exclusive sum over the flat counts; sorted_base_kernel picks the per-read bases out of it
+//   sorted_emit_kernel   one lane per emitting query: left extension and the match records
+struct SortedRec { int32_t read, start, end, depth, prefix, pad; };
+
+__global__ __launch_bounds__(256) void sorted_keys_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
+                                                         const int64_t* __restrict__ qbase, uint32_t* __restrict__ keys,
+                                                         uint64_t* __restrict__ vals) {
+    const int r = blockIdx.x;
+    const SeedQ Q = qs[r];
+    const int64_t f0 = qbase[r];
+    PatD P;
+    P.len = Q.plen;
+    P.p = reads + Q.poff;
+    PrefixMap pm;
+    pm.step = Q.sparse_q * X.K;
+    pm.Lmax = Q.plen - (Q.min_len - (pm.step - 1));
+    pm.nh = Q.pm_nh; pm.kh = Q.pm_kh; pm.m1 = Q.pm_m1; pm.m2 = Q.pm_m2;
+    const bool use_kmer = Q.plen >= KMER;
+    for (int t = threadIdx.x; t < Q.npref; t += 256) {
+        const int pf = pm.prefix_of_fast(t);
+        uint32_t key = TABLE;                                   // no 10-mer jump: the descent starts at the root
+        if (use_kmer) {
+            const uint32_t index = pf + KMER <= Q.plen ? kmer_code(P, pf) : 0xFFFFFFFFu;
+            key = (index < TABLE && ((X.KBIT[index >> 5] >> (index & 31)) & 1u)) ? index : TABLE + 1;
+        }
+        keys[f0 + t] = key;
+        vals[f0 + t] = ((uint64_t)(uint32_t)r << 32) | (uint32_t)t;
+    }
+}
+
+__global__ __launch_bounds__(256) void sorted_eval_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
+                                                         const int64_t* __restrict__ qbase, const uint32_t* __restrict__ keys,
+                                                         const uint64_t* __restrict__ vals, int64_t total, int64_t* __restrict__ cnt_out,
+                                                         SortedRec* __restrict__ rec) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= total) return;
+    const uint32_t key = keys[s];
+    const uint64_t v = vals[s];
+    const int r = (int)(v >> 32), t = (int)(uint32_t)v;
+    const int64_t f = qbase[r] + t;
+    if (key > TABLE) { cnt_out[f] = 0; return; }
+    const SeedQ Q = qs[r];
+    PrefixMap pm;
+    pm.step = Q.sparse_q * X.K;
+    pm.Lmax = Q.plen - (Q.min_len - (pm.step - 1));
+    pm.nh = Q.pm_nh; pm.kh = Q.pm_kh; pm.m1 = Q.pm_m1; pm.m2 = Q.pm_m2;
+    Q3 ent;
+    ent.read = r; ent.prefix = pm.prefix_of_fast(t); ent.start = 0; ent.end = X.n - 1; ent.z = 0; ent.w = 0;
+    if (key == TABLE) ent.prefix |= (int)0x80000000;
+    else {
+        const uint4 e = X.KMR2[key];
+        ent.start = (int)e.x; ent.end = (int)e.y; ent.z = e.z; ent.w = e.w;
+    }
+    int cnt, start, end, depth;
+    eval_entry(X, Q, reads, X.K, ent, cnt, start, end, depth);
+    cnt_out[f] = cnt;
+    if (cnt > 0) {
+        SortedRec o;
+        o.read = r; o.start = start; o.end = end; o.depth = depth; o.prefix = ent.prefix & 0x7fffffff; o.pad = 0;
+        rec[f] = o;
+    }
+}
+
+// read_base[r] = offset of read r's first match = the scanned count at the read's first flat index (read_base[nq] = total)
+__global__ void sorted_base_kernel(const int64_t* __restrict__ scan, const int64_t* __restrict__ cnt, const int64_t* __restrict__ qbase, int nq,
+                                   int64_t total_q, int64_t* __restrict__ read_base) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nq) return;
+    const int64_t f = qbase[r];
+    read_base[r] = f < total_q ? scan[f] : (total_q > 0 ? scan[total_q - 1] + cnt[total_q - 1] : 0);
+}
+
+__global__ __launch_bounds__(256) void sorted_emit_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
+                                                         const int64_t* __restrict__ scan, const int64_t* __restrict__ cnt,
+                                                         const SortedRec* __restrict__ rec, int64_t total_q, const int64_t* __restrict__ read_base,
+                                                         int nq, alfa_match* __restrict__ out, int64_t out_cap) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= total_q || read_base[nq] > out_cap || cnt[f] == 0) return;
+    const SortedRec w = rec[f];
+    const SeedQ Q = qs[w.read];
+    PatG P; P.p = reads + Q.poff; P.len = Q.plen;
+    const int K = X.K;
+    const int minMin_len = Q.sparse_q > 1 ? Q.min_len - K : Q.min_len;
+    const int border = Q.sparse_q * K;
+    alfa_match* o = out + scan[f];
+    for (int i = w.start; i <= w.end; ++i) {
+        int64_t mr; int mq, ml;
+        if (lmax_strict(X, P, w.prefix, (int64_t)X.SA[i], w.depth, minMin_len, border, mr, mq, ml)) {
+            alfa_match m; m.ref = mr; m.query = mq; m.len = ml;
+            *o++ = m;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- kernel A, plain form: one read per workgroup, every lane walks
 // its query to the end (used for indexes without a child table)
 __global__ __launch_bounds__(SEED_BLOCK) void smam_count_simple_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
@@ -878,13 +999,6 @@ __global__ __launch_bounds__(SEED_BLOCK) void smam_count_simple_kernel(DIdx X, c
     }
     if (tid == 0) read_total[r] = running;
 }
-
-struct PatG {   // read bytes straight from global memory (kernel B touches only a few of them)
-    const uint8_t* p;
-    int len;
-    __device__ __forceinline__ uint32_t at(int i) const { return (i >= 0 && i < len) ? p[i] : 0u; }
-    __device__ __forceinline__ uint64_t load8(int i) const { return ld8(p + i); }
-};
 
 // ---------------------------------------------------------------- kernel B: emit
 __global__ void smam_emit_kernel(DIdx X, const SeedQ* __restrict__ qs, const uint8_t* __restrict__ reads,
@@ -1529,6 +1643,7 @@ int alfa_index_upload(const alfa_index_view* v, int device, alfa_index** out) {
     if (ix->has_kmer) {
         // device-side companions of the 10-mer table (layout is ours; content is a function of KMR and SA only)
         std::vector<uint32_t> k2(4 * (size_t)TABLE), kb(TABLE / 32, 0u);
+        size_t nset = 0;
         for (size_t i = 0; i < TABLE; ++i) {
             const uint32_t l = v->KMR[2 * i], r = v->KMR[2 * i + 1];
             if (r > 0 && (l > r || r >= (uint64_t)v->n)) {
@@ -1540,8 +1655,9 @@ int alfa_index_upload(const alfa_index_view* v, int device, alfa_index** out) {
             if (r > l) nxt = (l + 1 < (uint64_t)v->n) ? v->SA[l + 1] : 0u;
             else if ((int64_t)sa + KMER + 4 <= v->N + 16) memcpy(&nxt, v->S + sa + KMER, 4);
             k2[4 * i] = l; k2[4 * i + 1] = r; k2[4 * i + 2] = sa; k2[4 * i + 3] = nxt;
-            if (r > 0) kb[i >> 5] |= 1u << (i & 31);
+            if (r > 0) { kb[i >> 5] |= 1u << (i & 31); ++nset; }
         }
+        ix->kbit_fill = (double)nset / (double)TABLE;
         if ((rc = upload(ix->KMR2, k2.data(), 16 * (size_t)TABLE)) || (rc = upload(ix->KBIT, kb.data(), TABLE / 8))) {
             alfa_index_free(ix);
             return rc;
@@ -1571,6 +1687,9 @@ struct alfa_seed_plan {
     int nseg = 1, seg_cap = 0;   // work list: nseg segments of seg_cap records (persistent SMAM kernel: one per workgroup)
     bool persistent = false;
     bool suflink = false;        // SMAM on a suffix-link index: (read, phase) chains, no work list
+    bool sorted = false;         // SMAM on an index beyond the caches: queries evaluated in 10-mer order (sorted_*_kernel)
+    size_t sort_tmp = 0;
+    alfa::DevBuf d_qbase, d_keys, d_keys2, d_vals, d_vals2, d_fcnt, d_fscan, d_frec, d_sorttmp;
     int stride = 0;              // persistent kernel: LDS bytes per wave for its read
     int64_t out_cap = 0;
     alfa::DevBuf d_reads, d_q, d_tot, d_base, d_work, d_cnt, d_out, d_tmp, d_scr, d_q3;
@@ -1679,6 +1798,30 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
     pl->suflink = (mem_type == ALFA_SEED_SMAM || mem_type == ALFA_SEED_MEM) && ix->has_suflink;
     pl->persistent = mem_type == ALFA_SEED_SMAM && ix->has_child && ix->has_kmer && !force_simple && magic_ok && !pl->suflink;
     if (pl->suflink && (rc = pl->d_scr.reserve(4 * (size_t)nq * (size_t)ix->K + 64))) return rc;
+    // indexes whose 10-mer table is (nearly) full: the bitmap filters nothing and the index is far beyond the caches
+    static const char* sorted_env = getenv("ALFA_SEED_SORTED");
+    pl->sorted = pl->persistent && total_pref > 0 && total_pref < 0x7fffffffLL &&
+                 (sorted_env ? atoi(sorted_env) != 0 : (ix->kbit_fill >= 0.9 && ix->n >= (1 << 21)));
+    if (pl->sorted) {
+        pl->persistent = false;
+        const size_t tp = (size_t)total_pref;
+        if ((rc = pl->d_qbase.reserve(8 * ((size_t)nq + 1))) || (rc = pl->d_keys.reserve(4 * tp)) || (rc = pl->d_keys2.reserve(4 * tp)) ||
+            (rc = pl->d_vals.reserve(8 * tp)) || (rc = pl->d_vals2.reserve(8 * tp)) || (rc = pl->d_fcnt.reserve(8 * tp)) ||
+            (rc = pl->d_fscan.reserve(8 * tp)) || (rc = pl->d_frec.reserve(sizeof(SortedRec) * tp)))
+            return rc;
+        size_t t1 = 0, t2 = 0;
+        ALFA_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t1, pl->d_keys.as<uint32_t>(), pl->d_keys2.as<uint32_t>(), pl->d_vals.as<uint64_t>(),
+                                                    pl->d_vals2.as<uint64_t>(), (int)tp, 0, 21, cx->stream));
+        ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, pl->d_fcnt.as<int64_t>(), pl->d_fscan.as<int64_t>(), (int)tp, cx->stream));
+        pl->sort_tmp = std::max(t1, t2) + 256;
+        if ((rc = pl->d_sorttmp.reserve(pl->sort_tmp))) return rc;
+        // per-read first flat index: staged behind the descriptors
+        if ((rc = cx->h_in2.reserve(8 * ((size_t)nq + 1)))) return rc;
+        int64_t* hb = cx->h_in2.as<int64_t>();
+        hb[0] = 0;
+        for (int i = 0; i < nq; ++i) hb[i + 1] = hb[i] + hq[i].npref;
+        ALFA_HIP(hipMemcpyAsync(pl->d_qbase.p, hb, 8 * ((size_t)nq + 1), hipMemcpyHostToDevice, cx->stream));
+    }
     pl->nseg = 1;
     if (pl->persistent) {
         static std::atomic<int> n_cu[64];          // several worker threads may get here at once: the set-up is idempotent
@@ -1725,6 +1868,26 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
     ALFA_HIP(hipMemsetAsync(d_cnt, 0, 4 * (size_t)pl->nseg, st));
     ALFA_HIP(hipMemsetAsync(d_tot, 0, 8 * ((size_t)nq + 1), st));       // the persistent kernel accumulates per-read totals
     ALFA_HIP(hipEventRecord(pl->ev0, st));
+    if (pl->sorted) {
+        const int64_t tp = pl->total_pref;
+        const int64_t* d_qbase = pl->d_qbase.as<int64_t>();
+        hipLaunchKernelGGL(sorted_keys_kernel, dim3(nq), dim3(256), 0, st, X, d_q, d_reads, d_qbase, pl->d_keys.as<uint32_t>(), pl->d_vals.as<uint64_t>());
+        size_t tb = pl->sort_tmp;
+        ALFA_HIP(hipcub::DeviceRadixSort::SortPairs(pl->d_sorttmp.p, tb, pl->d_keys.as<uint32_t>(), pl->d_keys2.as<uint32_t>(), pl->d_vals.as<uint64_t>(),
+                                                    pl->d_vals2.as<uint64_t>(), (int)tp, 0, 21, st));
+        hipLaunchKernelGGL(sorted_eval_kernel, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, st, X, d_q, d_reads, d_qbase, pl->d_keys2.as<uint32_t>(),
+                           pl->d_vals2.as<uint64_t>(), tp, pl->d_fcnt.as<int64_t>(), pl->d_frec.as<SortedRec>());
+        ALFA_HIP(hipGetLastError());
+        ALFA_HIP(hipEventRecord(pl->ev1, st));
+        tb = pl->sort_tmp;
+        ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_sorttmp.p, tb, pl->d_fcnt.as<int64_t>(), pl->d_fscan.as<int64_t>(), (int)tp, st));
+        hipLaunchKernelGGL(sorted_base_kernel, dim3((nq + 1 + 255) / 256), dim3(256), 0, st, pl->d_fscan.as<int64_t>(), pl->d_fcnt.as<int64_t>(), d_qbase, nq, tp,
+                           d_base);
+        hipLaunchKernelGGL(sorted_emit_kernel, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, st, X, d_q, d_reads, pl->d_fscan.as<int64_t>(),
+                           pl->d_fcnt.as<int64_t>(), pl->d_frec.as<SortedRec>(), tp, (const int64_t*)d_base, nq, pl->d_out.as<alfa_match>(), pl->out_cap);
+        ALFA_HIP(hipGetLastError());
+        return ALFA_OK;
+    }
     if (pl->suflink) {
         if (pl->mem_type == ALFA_SEED_SMAM)
             hipLaunchKernelGGL((smam_suflink_kernel<ALFA_SEED_SMAM, false>), dim3(nq), dim3(SEED_BLOCK), lds_bytes, st, X, d_q, d_reads, d_tot,
@@ -1821,6 +1984,7 @@ void plan_release(alfa_seed_plan* pl) {
     pl->d_reads.release(); pl->d_q.release(); pl->d_tot.release(); pl->d_base.release(); pl->d_work.release(); pl->d_out.release();
     pl->d_tmp.release(); pl->d_scr.release(); pl->d_cnt.release(); pl->d_q3.release();
     pl->d_reg.release(); pl->d_rm.release(); pl->d_aux.release();
+    for (alfa::DevBuf* b : {&pl->d_qbase, &pl->d_keys, &pl->d_keys2, &pl->d_vals, &pl->d_vals2, &pl->d_fcnt, &pl->d_fscan, &pl->d_frec, &pl->d_sorttmp}) b->release();
     if (pl->ev0) { (void)hipEventDestroy(pl->ev0); (void)hipEventDestroy(pl->ev1); pl->ev0 = pl->ev1 = nullptr; }
 }
 
@@ -1873,6 +2037,7 @@ int alfa_seed_plan_fetch(alfa_seed_plan* pl, alfa_match** matches, int64_t* offs
     return plan_fetch(pl, cx, matches, offsets);
 }
 int64_t alfa_seed_plan_queries(const alfa_seed_plan* pl) { return pl ? pl->total_pref : 0; }
+int alfa_seed_plan_sorted(const alfa_seed_plan* pl) { return pl && pl->sorted ? 1 : 0; }
 double alfa_seed_plan_kernel_ms(const alfa_seed_plan* pl) {
     if (!pl || !pl->launched || pl->nq == 0) return 0;
     float ms = 0;

@@ -525,6 +525,11 @@ class SeedPlan:
     def kernel_ms(self):
         return lib().alfa_seed_plan_kernel_ms(self._h)
 
+    @property
+    def sorted(self):
+        """queries evaluated in 10-mer order (the path for indexes beyond the caches)"""
+        return bool(lib().alfa_seed_plan_sorted(self._h))
+
     def __del__(self):
         try:
             if self._h:

@@ -398,7 +398,8 @@ def main():
         if prof:
             pj = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
             if pj.get("batch") == args.batch and (c4 or (args.ref_len == 5000000 and args.read_len == 250)):
-                traffic = pj["bytes_per_dispatch"].get("smam_count_kernel")
+                bd = pj["bytes_per_dispatch"]
+                traffic = bd.get("smam_seed_path", bd.get("smam_count_kernel"))
     except Exception:
         traffic = None
 
@@ -603,7 +604,8 @@ def main():
         "seeds_per_read": seeds_per_read,
         "index_build_s": t_index,
         "roofline": {
-            "kernel": "smam_count_kernel",
+            "kernel": ("sorted_keys_kernel + hipCUB radix sort + sorted_eval_kernel (queries in 10-mer order: the index is beyond the caches)"
+                       if timed[0][0].sorted else "smam_count_kernel"),
             "bound": "hbm",
             "limiter": "latency / instruction issue, not bandwidth: a gather kernel (FETCH_SIZE = algorithmic bytes, L2 hit rate "
                        "and wave wait fraction in profiles/*_seed_limiter.json)",

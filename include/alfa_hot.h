@@ -223,6 +223,9 @@ int     alfa_seed_plan_create(alfa_index*, int mem_type, const alfa_seed_query* 
 int     alfa_seed_plan_launch(alfa_seed_plan*);
 int     alfa_seed_plan_fetch(alfa_seed_plan*, alfa_match** matches, int64_t* offsets);
 int64_t alfa_seed_plan_queries(const alfa_seed_plan*);   /* number of (read,prefix) traversals */
+/* 1 when the plan evaluates its queries in 10-mer order (SMAM on an index whose 10-mer table is >= 90 % full and that has
+ * >= 2^21 sampled suffixes: far beyond the caches; sorted_*_kernel in seed_kernels.hip), else 0.  Results are identical. */
+int     alfa_seed_plan_sorted(const alfa_seed_plan*);
 double  alfa_seed_plan_kernel_ms(const alfa_seed_plan*); /* HIP-event time of the traversal kernel of the last launch */
 void    alfa_seed_plan_free(alfa_seed_plan*);
 

@@ -283,3 +283,36 @@ def test_short_lived_threads_give_their_memory_back(gpu):
     ffi.sync(0)                 # any library call on a live thread releases what the finished threads left behind
     after = free_bytes()
     assert before - after < (8 << 20), (before, after)      # each thread used ~100 MB while it lived
+
+
+def test_smam_sorted_path_on_a_big_index(gpu):
+    """an index whose 10-mer table is full and that is far beyond the caches (40 Mbp at K = 12: 3.3 M sampled suffixes) takes the
+    sorted path -- queries evaluated in 10-mer order, offsets from one scan over the flat counts -- with identical results"""
+    import seqgen
+    import oracle_ffi as O
+    rng = np.random.default_rng(31)
+    ref = seqgen.rand_ref(rng, 40000000)
+    ffi.index_build_on_device(0)
+    try:
+        hidx = ffi.HostIndex.build_mem(["chr1"], [ref], K=12)
+    finally:
+        ffi.index_build_on_device(-1)
+    didx = ffi.DeviceIndex(hidx, 0)
+    reads = seqgen.sim_reads(rng, ref, 400, 100, 400, 0.03) + seqgen.sim_reads(rng, ref, 30, 2000, 9000, 0.10)
+    reads += [b"", b"acgt", ref[:9], b"n" * 50, ref[5000:5200].replace(b"a", b"n", 3)]
+    reads = reads + [seqgen.revcomp(r) for r in reads]
+    for min_len, sq in ((20, 1), (40, 2), (60, 4)):
+        q = ffi.make_seed_queries(reads, min_len, 10000, sq)
+        plan = ffi.SeedPlan(didx, ffi.SEED_SMAM, q)
+        assert plan.sorted
+        plan.launch()
+        m, off = plan.fetch()
+        mo, oo = O.orc_seed_batch(hidx.view, ffi.SEED_SMAM, q)
+        assert np.array_equal(off, oo), (min_len, sq)
+        assert np.array_equal(m, mo), (min_len, sq)
+        assert len(m) > 50
+    # small maxCount (interval size filter) and the synchronous entry point
+    q = ffi.make_seed_queries(reads, 25, 2, 1)
+    m, off = didx.seed_batch(ffi.SEED_SMAM, q)
+    mo, oo = O.orc_seed_batch(hidx.view, ffi.SEED_SMAM, q)
+    assert np.array_equal(off, oo) and np.array_equal(m, mo)
