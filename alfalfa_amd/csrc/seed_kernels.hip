@@ -674,11 +674,91 @@ __global__ __launch_bounds__(PBLOCK) void smam_count_kernel(DIdx X, const SeedQ*
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (moves) q3[lane] = mv;                               // the rest of the queue moves to the front
         q3n -= take;
+        // (the body of eval_entry, kept in line: this kernel sits on the 128-register budget of a 16-wave workgroup and the
+        // call, although inlined, made the allocator spill 19 registers: 0.31 -> 0.44 ms)
         int cnt = 0, start = ent.start, end = ent.end, depth = 0;
         const int prefix = ent.prefix & 0x7fffffff;
         if (have) {
             const SeedQ Q = qs[ent.read];
-            eval_entry(X, Q, reads, K, ent, cnt, start, end, depth);
+            PatD P;
+            P.len = Q.plen;
+            P.p = reads + Q.poff;                               // the read's LDS copy may be gone: global bytes
+            const int step = Q.sparse_q * K;
+            const int min_lenK = Q.min_len - (step - 1);
+            const int minMin_len = Q.sparse_q > 1 ? Q.min_len - K : Q.min_len;
+            const int maxCount = Q.sparse_q * Q.max_count;
+            // Hits with 1..4 sampled suffixes behind the 10-mer (all but a fraction of a percent on a non-repetitive
+            // reference) are evaluated directly.  The child-table descent reaches, by construction, the deepest match M of
+            // P[prefix..] among the suffixes of the interval and ends on the sub-interval of the suffixes that attain it (at a
+            // branching node when no child continues P, inside an edge on a mismatch, or at the end of the read or text):
+            // with so few suffixes, M follows from comparing each of them with the read, all text chunks being independent
+            // loads (16 bytes per suffix and round trip) instead of ~10 dependent CHILD/LCP/SA/S probes.  A single suffix
+            // is the run of comparisons of :758,:781-786.
+            int64_t sas[4] = {0, 0, 0, 0};
+            int lim[4] = {-1, -1, -1, -1}, mi[4] = {-1, -1, -1, -1};     // -1: unused slot
+            bool go[4] = {false, false, false, false};
+            bool direct = false;
+            const int c0 = prefix + KMER;
+            if (ent.prefix >= 0) {
+                depth = KMER;
+                const int nsuf = end - start + 1;
+                if (nsuf >= 1 && nsuf <= 4) {
+                    direct = true;
+                    sas[0] = (int64_t)ent.z;
+                    if (nsuf >= 2) sas[1] = (int64_t)ent.w;
+                    if (nsuf >= 3) sas[2] = (int64_t)X.SA[start + 2];
+                    if (nsuf >= 4) sas[3] = (int64_t)X.SA[start + 3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < nsuf) {
+                            lim[k] = (int)max((int64_t)0, min((int64_t)(Q.plen - c0), X.N - (sas[k] + KMER)));
+                            mi[k] = 0;
+                            go[k] = lim[k] > 0;
+                        }
+                }
+            }
+            if (direct) {
+                for (int off = 0; go[0] || go[1] || go[2] || go[3]; off += 16) {
+                    uint64_t a0[4], a1[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (go[k]) { a0[k] = ld8(X.S + sas[k] + KMER + off); a1[k] = ld8(X.S + sas[k] + KMER + off + 8); }
+                    const uint64_t b0 = P.load8(c0 + off), b1 = P.load8(c0 + off + 8);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (go[k]) {
+                            const uint64_t x0 = a0[k] ^ b0, x1 = a1[k] ^ b1;
+                            int m = 16;
+                            if (x0) m = __builtin_ctzll(x0) >> 3;
+                            else if (x1) m = 8 + (__builtin_ctzll(x1) >> 3);
+                            if (!(m >= 16 && lim[k] > off + 16)) { mi[k] = min(off + m, lim[k]); go[k] = false; }
+                        }
+                }
+                const int M = max(max(mi[0], mi[1]), max(mi[2], mi[3]));
+                int ns = 3, ne = 0;
+#pragma unroll
+                for (int k = 3; k >= 0; --k) if (mi[k] == M) ns = k;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (mi[k] == M) ne = k;
+                depth = KMER + M;
+                end = start + ne; start = start + ns;
+                // keep the SA values of the surviving suffixes addressable by (rank - start)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) if (ns > k) { sas[0] = sas[1]; sas[1] = sas[2]; sas[2] = sas[3]; }
+            } else {
+                traverse_from(X, P, prefix, start, end, depth, Q.plen, -1);
+            }
+            if (depth > 1 && depth >= min_lenK && (end - start + 1) <= maxCount) {
+                int64_t mr; int mq, ml;
+                if (direct) {
+                    for (int k = 0; k <= end - start; ++k) {
+                        const int64_t sk = k == 0 ? sas[0] : k == 1 ? sas[1] : k == 2 ? sas[2] : sas[3];
+                        cnt += lmax_strict(X, P, prefix, sk, depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
+                    }
+                } else
+                    for (int i = start; i <= end; ++i)
+                        cnt += lmax_strict(X, P, prefix, (int64_t)X.SA[i], depth, minMin_len, step, mr, mq, ml) ? 1 : 0;
+            }
         }
         // offsets: an exclusive scan over the wave, made relative to the first entry of the same read, plus what earlier
         // evaluations already handed out inside that read
