@@ -50,7 +50,7 @@ struct Ctx {
     static constexpr int NSIDE = 14;
     hipStream_t side[NSIDE] = {};
     hipEvent_t side_ev[NSIDE] = {};
-    hipEvent_t l2_ev[6] = {};        // a ksw_lane2 class of a ksw_extend batch is done (its give-up list is complete)
+    hipEvent_t l2_ev[6] = {};        // spare
     hipEvent_t fill_ev[3] = {};      // a group bin's fill kernel is done: its two backtrack classes may run side by side
     hipEvent_t fork_ev = nullptr;
     // lazy join (alfa_set_lazy_join): launches leave their side chains unjoined so that successive batches overlap; the
