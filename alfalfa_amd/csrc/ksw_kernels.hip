@@ -1730,11 +1730,17 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         DevTask& d = ht[k];
         memset(&d, 0, sizeof(d));
         d.qoff = (int64_t)so;
-        for (int j = 0; j < x.qlen; ++j) { const uint8_t c = x.query[j]; if (c >= m) return alfa::fail(ALFA_EINVAL, "query residue code >= m"); hs[so + j] = c; }
-        so += (size_t)x.qlen;
+        // copy, then one branch-free pass for the range check (the compiler vectorises both)
+        auto pack = [&](const uint8_t* src, int len) -> bool {
+            memcpy(hs + so, src, (size_t)len);
+            unsigned bad = 0;
+            for (int j = 0; j < len; ++j) bad |= (unsigned)(src[j] >= m);
+            so += (size_t)len;
+            return bad == 0;
+        };
+        if (!pack(x.query, x.qlen)) return alfa::fail(ALFA_EINVAL, "query residue code >= m");
         d.toff = (int64_t)so;
-        for (int j = 0; j < x.tlen; ++j) { const uint8_t c = x.target[j]; if (c >= m) return alfa::fail(ALFA_EINVAL, "target residue code >= m"); hs[so + j] = c; }
-        so += (size_t)x.tlen;
+        if (!pack(x.target, x.tlen)) return alfa::fail(ALFA_EINVAL, "target residue code >= m");
         d.qlen = x.qlen; d.tlen = rows_eff[li]; d.w = w_eff[li]; d.h0 = x.h0; d.orig = k;
         b->dense_of[k] = li;
         if (bins[li] == 8) { d.ehoff = b->eh_items; b->eh_items += (int64_t)x.qlen + 2; }
