@@ -44,6 +44,7 @@ struct Timing {
 struct Ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t up = nullptr;        // host-to-device staging copies: waited for by the host alone, never behind running kernels
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // side streams: independent kernel chains of one batch (one per kernel bin) fork from `stream` and join it again,
     // so that a bin holding a handful of long tasks does not serialise behind (or in front of) the others

@@ -79,6 +79,7 @@ Ctx::~Ctx() {
     if (fork_ev) (void)hipEventDestroy(fork_ev);
     for (DevBuf* b : {&d_in, &d_in2, &d_tasks, &d_out, &d_out2, &d_scratch, &d_z, &d_cnt, &d_off, &d_ivl}) b->release();
     for (PinBuf* b : {&h_in, &h_in2, &h_tasks, &h_out, &h_out2}) b->release();
+    if (up) (void)hipStreamDestroy(up);
     (void)hipStreamDestroy(stream);
     stream = nullptr;
 }
@@ -95,6 +96,7 @@ int Ctx::ensure(int dev) {
         hipStream_t main_stream = nullptr;
         hipError_t err = hipStreamCreateWithFlags(&main_stream, hipStreamNonBlocking);
         auto ok = [&](hipError_t e) { if (err == hipSuccess) err = e; return err == hipSuccess; };
+        (void)ok(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
         for (auto& e : ev) if (!ok(hipEventCreate(&e))) break;
         for (auto& st : side) if (!ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking))) break;
         for (auto& e : side_ev) if (!ok(hipEventCreateWithFlags(&e, hipEventDisableTiming))) break;
@@ -108,6 +110,7 @@ int Ctx::ensure(int dev) {
             for (auto& e : fill_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
             for (auto& e : l2_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
             if (fork_ev) { (void)hipEventDestroy(fork_ev); fork_ev = nullptr; }
+            if (up) { (void)hipStreamDestroy(up); up = nullptr; }
             if (main_stream) (void)hipStreamDestroy(main_stream);
             return fail(ALFA_EHIP, std::string("creating the context's streams and events: ") + hipGetErrorString(err));
         }

@@ -27,6 +27,7 @@
 //     lane-per-task kernel that follows the reference loop literally (the rare tail).
 //   * The kernel bins of a batch run as independent chains on side streams (launch_all).
 #include <algorithm>
+#include <memory>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -1807,7 +1808,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
     }
     if (mode == MODE_EXTEND && n_l2) {
         if ((rc = b->d_bail.reserve(256))) return rc;
-        ALFA_HIP(hipMemsetAsync(b->d_bail.p, 0, 256, cx->stream));       // synchronised with the copies below
+        ALFA_HIP(hipMemsetAsync(b->d_bail.p, 0, 256, cx->up));           // synchronised with the copies below
         b->launches = 0;
     }
     b->out_bytes = (mode == MODE_EXTEND ? sizeof(ExtOut) : sizeof(int32_t)) * (size_t)n;
@@ -1817,7 +1818,8 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         const size_t cb = 4 * (size_t)b->cig_words + 4 * (size_t)n;
         if ((rc = b->d_z.reserve((size_t)b->zbytes + 64)) || (rc = b->d_cig.reserve(cb)) || (rc = b->h_cig.reserve(cb))) return rc;
     }
-    hipStream_t st = cx->stream;
+    // on the upload stream: the host waits for these copies only, not for kernels of other calls still running on cx->stream
+    hipStream_t st = cx->up;
     ALFA_HIP(hipMemcpyAsync(b->d_seq.p, hs, seq_bytes + 16, hipMemcpyHostToDevice, st));
     ALFA_HIP(hipMemcpyAsync(b->d_tasks.p, hprm, sizeof(DevParams) + sizeof(DevTask) * (size_t)n, hipMemcpyHostToDevice, st));
     ALFA_HIP(hipStreamSynchronize(st));   // staging buffers of the context are free again
@@ -1908,6 +1910,28 @@ int pack_cigars(const std::vector<std::vector<uint32_t>>& cigs, int n, uint32_t*
 }
 
 // synchronous call: chunks of bounded device footprint through one per-thread reusable batch object
+// the calling thread's recycled batch of a ksw kind; buried when the thread ends (device_ctx.h: a live thread releases it)
+alfa_dp_batch* thread_batch(int mode) {
+    struct Reuse {
+        alfa_dp_batch* b[3] = {nullptr, nullptr, nullptr};
+        ~Reuse() {
+            for (auto*& x : b)
+                if (x) {
+                    alfa::bury([](void* p) { alfa_dp_batch* d = (alfa_dp_batch*)p; (void)hipSetDevice(d->device); release_batch(d); delete d; }, x);
+                    x = nullptr;
+                }
+        }
+    };
+    thread_local Reuse reuse;
+    if (!reuse.b[mode]) reuse.b[mode] = new alfa_dp_batch();
+    return reuse.b[mode];
+}
+
+constexpr int64_t SYNC_LIMIT = (int64_t)6 << 30;      // device bytes of one batch of the synchronous calls
+int64_t sync_need(int mode, const alfa_dp_task& x) {
+    return (mode == MODE_GLOBAL ? (int64_t)x.tlen * 256 + 4 * ((int64_t)x.qlen + x.tlen) : 0) + (int64_t)x.qlen + x.tlen;
+}
+
 int run_sync(int mode, const alfa_dp_params* p, const alfa_dp_task* t, int n, void* out, uint32_t** cigar, int32_t* ncig, int64_t* cig_off) {
     alfa::g_last_timing = alfa::Timing();
     if (n < 0 || (n > 0 && (!t || !out))) return alfa::fail(ALFA_EINVAL, "null task/result array");
@@ -1920,21 +1944,8 @@ int run_sync(int mode, const alfa_dp_params* p, const alfa_dp_task* t, int n, vo
     if (n > 0) {
         Ctx* cx;
         if ((rc = current_ctx(&cx))) return rc;
-        // recycled from call to call; buried when the thread ends (device_ctx.h: a live thread releases them)
-        struct Reuse {
-            alfa_dp_batch* b[3] = {nullptr, nullptr, nullptr};
-            ~Reuse() {
-                for (auto*& x : b)
-                    if (x) {
-                        alfa::bury([](void* p) { alfa_dp_batch* d = (alfa_dp_batch*)p; (void)hipSetDevice(d->device); release_batch(d); delete d; }, x);
-                        x = nullptr;
-                    }
-            }
-        };
-        thread_local Reuse reuse;
-        if (!reuse.b[mode]) reuse.b[mode] = new alfa_dp_batch();
-        alfa_dp_batch* b = reuse.b[mode];
-        const int64_t LIMIT = (int64_t)6 << 30;
+        alfa_dp_batch* b = thread_batch(mode);
+        const int64_t LIMIT = SYNC_LIMIT;
         std::vector<int> ids;
         int64_t need = 0;
         auto flush = [&]() -> int {
@@ -1950,8 +1961,7 @@ int run_sync(int mode, const alfa_dp_params* p, const alfa_dp_task* t, int n, vo
             return ALFA_OK;
         };
         for (int i = 0; i < n; ++i) {
-            int64_t z = mode == MODE_GLOBAL ? (int64_t)t[i].tlen * 256 + 4 * ((int64_t)t[i].qlen + t[i].tlen) : 0;
-            z += (int64_t)t[i].qlen + t[i].tlen;
+            const int64_t z = sync_need(mode, t[i]);
             if (!ids.empty() && need + z > LIMIT) { if ((rc = flush())) return rc; }
             ids.push_back(i);
             need += z;

@@ -1900,7 +1900,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
         int64_t* hb = cx->h_in2.as<int64_t>();
         hb[0] = 0;
         for (int i = 0; i < nq; ++i) hb[i + 1] = hb[i] + hq[i].npref;
-        ALFA_HIP(hipMemcpyAsync(pl->d_qbase.p, hb, 8 * ((size_t)nq + 1), hipMemcpyHostToDevice, cx->stream));
+        ALFA_HIP(hipMemcpyAsync(pl->d_qbase.p, hb, 8 * ((size_t)nq + 1), hipMemcpyHostToDevice, cx->up));
     }
     pl->nseg = 1;
     if (pl->persistent) {
@@ -1926,9 +1926,10 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
     if ((rc = pl->d_work.reserve(pl->work_rec * (size_t)pl->nseg * (size_t)pl->seg_cap + 64)) || (rc = pl->d_cnt.reserve(4 * (size_t)pl->nseg + 64)) ||
         (rc = pl->d_out.reserve(sizeof(alfa_match) * (size_t)pl->out_cap)) || (rc = pl->d_tmp.reserve(pl->tmp_bytes + 64)))
         return rc;
-    ALFA_HIP(hipMemcpyAsync(pl->d_reads.p, hp, bytes, hipMemcpyHostToDevice, cx->stream));
-    ALFA_HIP(hipMemcpyAsync(pl->d_q.p, hq, sizeof(SeedQ) * (size_t)nq, hipMemcpyHostToDevice, cx->stream));
-    ALFA_HIP(hipStreamSynchronize(cx->stream));
+    // on the upload stream: the host waits for these copies only, not for kernels of other calls still running on cx->stream
+    ALFA_HIP(hipMemcpyAsync(pl->d_reads.p, hp, bytes, hipMemcpyHostToDevice, cx->up));
+    ALFA_HIP(hipMemcpyAsync(pl->d_q.p, hq, sizeof(SeedQ) * (size_t)nq, hipMemcpyHostToDevice, cx->up));
+    ALFA_HIP(hipStreamSynchronize(cx->up));
     return ALFA_OK;
 }
 
