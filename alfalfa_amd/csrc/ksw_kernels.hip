@@ -1561,7 +1561,7 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
     // Every bin is an independent chain (fill kernel -> backtrack): the chains fork onto side streams and join again.
     // Tasks of a bin are ordered by tlen, longest first: the first nbig direction matrices exceed ZC bytes (their backtrack
     // walks HBM), the rest fit ZC (LDS slices); the two backtrack classes of a bin run side by side.
-    // streams: 0-2 group bins, 3 the 128-diagonal wave bin, 5-7 the LDS backtracks of the group bins, 8-9 ksw_lane2_kernel; the
+    // streams: 0-2 group bins, 3 the 128-diagonal wave bin (10 for ksw_extend), 5-7 the LDS backtracks of the group bins, 8-9 ksw_lane2_kernel; the
     // 256-diagonal wave bin (long reads: few, long-running wavefronts whose launch is mostly a latency tail) gets a stream per
     // ksw kind -- 4 nw, 11 extend, 13 global -- so that, with lazy joins, the tails of successive batches overlap instead of
     // queueing up (C4 step 20.2 -> 13 ms).  Which streams share one of the 4 hardware queues matters: moving the 128-diagonal
@@ -1603,7 +1603,7 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
     }
     // bands of up to 128 / 256 diagonals: a whole wavefront per task
     if (bc[6]) {
-        hipStream_t s2 = side(3);
+        hipStream_t s2 = side(MODE == MODE_EXTEND ? 10 : 3);
         launch_wave<MODE, 2>(s2, d_t + o, bc[6], d_seq, d_prm, d_out, d_z);
         if (MODE == MODE_GLOBAL)
             hipLaunchKernelGGL(ksw_backtrack_tile_kernel, dim3(bc[6]), dim3(64), 0, s2, d_t + o, bc[6], d_z, d_cig, d_ncig, 64 * 2);
