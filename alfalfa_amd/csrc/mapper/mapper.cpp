@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <list>
+#include <mutex>
 #include <map>
 #include <charconv>
 #include <type_traits>
@@ -384,9 +385,26 @@ void Mapper::cand_regions(const Read& read, std::vector<Lis>& lis, double errorP
     }
     seeds_both_strands(P, Prc, min_len, matches, matchesRC);
     if (matches.size() > 0 || matchesRC.size() > 0) {
+        // ALFA_REGION_LOG=<file> (tests): the seeds of both strands and the regions built from them, as text -- what
+        // oracle/regions_oracle.py is checked against on the CPU
+        static FILE* rlog = getenv("ALFA_REGION_LOG") ? fopen(getenv("ALFA_REGION_LOG"), "w") : nullptr;
+        static std::mutex rlog_mu;
+        std::vector<Match> in_fw, in_rc;
+        if (rlog) { in_fw = matches; in_rc = matchesRC; }
         identify_and_filter(matches, true, Plength, editDist, lis);
         identify_and_filter(matchesRC, false, Plength, editDist, lis);
         for (size_t i = 0; i < lis.size(); i++) lis[i].score = covered_bases(lis[i].matches);
+        if (rlog) {
+            std::lock_guard<std::mutex> g(rlog_mu);
+            fprintf(rlog, "R %d %d %zu %zu %zu\n", Plength, editDist, in_fw.size(), in_rc.size(), lis.size());
+            for (const Match& m : in_fw) fprintf(rlog, "%lld %d %d\n", (long long)m.ref, m.query, m.len);
+            for (const Match& m : in_rc) fprintf(rlog, "%lld %d %d\n", (long long)m.ref, m.query, m.len);
+            for (const Lis& l : lis) {
+                fprintf(rlog, "G %d %lld %lld %d %zu\n", l.fw ? 1 : 0, (long long)l.refBegin, (long long)l.refEnd, l.score, l.matches.size());
+                for (const Match& m : l.matches) fprintf(rlog, "%lld %d %d\n", (long long)m.ref, m.query, m.len);
+            }
+            fflush(rlog);
+        }
         std::sort(lis.begin(), lis.end(), [](const Lis& a, const Lis& b) { return a.score > b.score; });   // compIntervals :1114
     }
 }

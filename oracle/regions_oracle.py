@@ -3,9 +3,11 @@ of alfa_seed_regions_batch.  Pure Python, for the few thousan
 
   identify_and_filter   identifyAndFilter  /root/reference/src/mapper.cpp:578-704
   covered_bases         coveredBases       /root/reference/src/mapper.cpp:706-719
-Pinned through the product: the host mapper's C++ restatement of the same two functions (alfalfa_amd/csrc/mapper/mapper.cpp)
-writes SAM that is byte-identical to the compiled reference's (tests/test_mapper_cpu.py), and this file is compared with the
-regions that mapper path consumes (tests/test_gpu_regions.py runs the command line with and without --device-regions).
+Pinned through the host mapper: its C++ restatement of the same two functions (alfalfa_amd/csrc/mapper/mapper.cpp) writes SAM
+that is byte-identical to the compiled reference's (tests/test_mapper_cpu.py), and tests/test_regions_oracle.py compares this
+file with the regions that code builds for every read of the lambda examples and of the synthetic set (ALFA_REGION_LOG), on the
+CPU.  tests/test_gpu_regions.py then checks the device kernel against this file and the command line with --device-regions
+against the reference's SAM.
 
 std::sort is not stable: where elements compare equal under the reference's comparator but differ, the reference's own order
 is an accident of the library.  `ambiguous` is set for such a strand; the device hands those back to the host (status 1)."""
