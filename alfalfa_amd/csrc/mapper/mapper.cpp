@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <list>
 #include <mutex>
 #include <map>
@@ -106,9 +107,10 @@ std::string cigar3_from4(const std::string& c4) {
     long matchLength = 0;
     while (p < c4.size()) {
         size_t q = p;
-        while (q < c4.size() && c4[q] >= '0' && c4[q] <= '9') q++;
+        long long nn = 0;
+        while (q < c4.size() && c4[q] >= '0' && c4[q] <= '9') { nn = nn * 10 + (c4[q] - '0'); q++; }
         if (q == p || q >= c4.size()) break;
-        int n = atoi(c4.substr(p, q - p).c_str());
+        int n = (int)nn;
         char sym = c4[q];
         if (sym == 'X' || sym == '=') matchLength += n;
         else {
@@ -385,8 +387,8 @@ void Mapper::cand_regions(const Read& read, std::vector<Lis>& lis, double errorP
     }
     seeds_both_strands(P, Prc, min_len, matches, matchesRC);
     if (matches.size() > 0 || matchesRC.size() > 0) {
-        // ALFA_REGION_LOG=<file> (tests): the seeds of both strands and the regions built from them, as text -- what
-        // oracle/regions_oracle.py is checked against on the CPU
+        // ALFA_REGION_LOG=<file> (diagnostics; tests/test_regions_oracle.py reads it): the seeds of both strands and the regions
+        // built from them, as text
         static FILE* rlog = getenv("ALFA_REGION_LOG") ? fopen(getenv("ALFA_REGION_LOG"), "w") : nullptr;
         static std::mutex rlog_mu;
         std::vector<Match> in_fw, in_rc;
@@ -753,7 +755,7 @@ void Mapper::postprocess(Read& read, bool paired) {
     struct DpJob { std::vector<uint32_t> cigar; int32_t score; const uint8_t* q; const uint8_t* t; };
     struct Plan { std::vector<uint8_t> target; std::vector<Piece> pieces; bool full = false; int fullJob = -1; };
     std::vector<Plan> plans((size_t)maxDP);
-    std::list<DpJob> jobs;
+    std::deque<DpJob> jobs;               // references stay valid across push_back (the scheduler holds pointers into the jobs)
     std::vector<DpJob*> jobv;
     auto add_job = [&](const uint8_t* q, int qLen, const uint8_t* t, int tLen, int band) {
         jobs.emplace_back();
