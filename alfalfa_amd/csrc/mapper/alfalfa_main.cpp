@@ -25,8 +25,8 @@ int main(int argc, char** argv) {
             return alfa_seed_batch((alfa_index*)ix, type, q, nq, m, off);
         };
         ops->seed_regions_batch = [](void* ix, int type, const alfa_seed_query* q, const int32_t* ed, int nq, const alfa_region_params* p, alfa_match** m,
-                                     int64_t* off, alfa_region** reg, int64_t* roff, alfa_match** mem, int64_t* boff, int32_t* st) {
-            return alfa_seed_regions_batch((alfa_index*)ix, type, q, ed, nq, p, m, off, reg, roff, mem, boff, st);
+                                     int64_t* off, alfa_region** reg, int64_t* roff, alfa_match** mem, int64_t* boff, int32_t** chn, int32_t* st) {
+            return alfa_seed_regions_batch((alfa_index*)ix, type, q, ed, nq, p, m, off, reg, roff, mem, boff, chn, st);
         };
         ops->ksw_extend_batch = alfa_ksw_extend_batch;
         ops->ksw_nw_batch = alfa_ksw_nw_batch;

@@ -162,10 +162,11 @@ void HotSched::flush() {
             const size_t nq = q.size();
             alfa_match *m = nullptr, *mem = nullptr;
             alfa_region* reg = nullptr;
+            int32_t* chn = nullptr;
             std::vector<int64_t> off(nq + 1), roff(nq + 1), boff(nq + 1);
             std::vector<int32_t> st(nq);
             int rc = ops_.seed_regions_batch(ops_.index, type, q.data(), ed.data(), (int)nq, &seedreg_[who[0]].prm, &m, off.data(), &reg, roff.data(),
-                                             &mem, boff.data(), st.data());
+                                             &mem, boff.data(), &chn, st.data());
             if (rc) die(ops_, "alfa_seed_regions_batch", rc);
             for (size_t k = 0; k < nq; ++k) {
                 const SeedRegionReq& r = seedreg_[who[k]];
@@ -181,10 +182,12 @@ void HotSched::flush() {
                         o.refBegin = reg[j].ref_begin; o.refEnd = reg[j].ref_end; o.score = reg[j].score;
                         o.matches.resize((size_t)reg[j].count);
                         memcpy((void*)o.matches.data(), mem + boff[k] + reg[j].first, sizeof(Match) * (size_t)reg[j].count);
+                        o.chain.assign(chn + boff[k] + reg[j].first, chn + boff[k] + reg[j].first + reg[j].chain_count);
+                        o.chainAnchor = reg[j].chain_anchor; o.chainEdit = reg[j].chain_edit; o.chainCoverage = reg[j].chain_coverage;
                     }
                 }
             }
-            ops_.free_fn(m); ops_.free_fn(reg); ops_.free_fn(mem);
+            ops_.free_fn(m); ops_.free_fn(reg); ops_.free_fn(mem); ops_.free_fn(chn);
             stats_.seed_calls++;
             stats_.seed_queries += (int64_t)nq;
         }

@@ -25,7 +25,7 @@ struct HotOps {
     int (*seed_batch)(void*, int, const alfa_seed_query*, int, alfa_match**, int64_t*) = nullptr;
     // optional: seeds and the candidate regions built from them in one call; nullptr = the mapper builds them
     int (*seed_regions_batch)(void*, int, const alfa_seed_query*, const int32_t*, int, const alfa_region_params*, alfa_match**, int64_t*,
-                              alfa_region**, int64_t*, alfa_match**, int64_t*, int32_t*) = nullptr;
+                              alfa_region**, int64_t*, alfa_match**, int64_t*, int32_t**, int32_t*) = nullptr;
     int (*ksw_extend_batch)(const alfa_dp_params*, const alfa_dp_task*, int, alfa_extend_result*) = nullptr;
     int (*ksw_nw_batch)(const alfa_dp_params*, const alfa_dp_task*, int, int32_t*) = nullptr;
     int (*ksw_global_batch)(const alfa_dp_params*, const alfa_dp_task*, int, int32_t*, uint32_t**, int32_t*, int64_t*) = nullptr;
@@ -40,7 +40,8 @@ struct SeedReq {
     const std::string* P; int min_len, max_count, sparse_q, mem_type, max_smem; std::vector<Match>* out;
 };
 // a region as identifyAndFilter + coveredBases leave it (lis_t without the bookkeeping fields)
-struct RegionOut { int64_t refBegin, refEnd; int score; std::vector<Match> matches; };
+// chain: the chain extendChain builds first in the region (member indices, nextChain's edit estimate and coverage, the anchor)
+struct RegionOut { int64_t refBegin, refEnd; int score; std::vector<Match> matches; std::vector<int32_t> chain; int chainAnchor, chainEdit, chainCoverage; };
 // one strand: seeds and, when the hot path could build them (*status == 0), its candidate regions in creation order
 struct SeedRegionReq {
     const std::string* P; int min_len, max_count, sparse_q, mem_type, max_smem, edit_dist; alfa_region_params prm;

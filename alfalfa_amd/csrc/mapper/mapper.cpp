@@ -352,7 +352,7 @@ void Mapper::cand_regions(const Read& read, std::vector<Lis>& lis, double errorP
         const int K = (int)idx_.K();
         int sparseSkip = K >= 4 ? std::max((min_len - 10) / K, 1) : std::max((min_len - 12) / K, 1);
         if (opt_.noSparseQ) sparseSkip = 1;
-        const alfa_region_params rp{opt_.maxSeedCandidates, opt_.maxRegionMems, opt_.minMemRegLength};
+        const alfa_region_params rp{opt_.maxSeedCandidates, opt_.maxRegionMems, opt_.minMemRegLength, 0, opt_.errorPercent};
         auto both = [&](int ml, int maxBranch, int skip) {
             if (!opt_.noFW) hot_.submit_seed_regions(SeedRegionReq{&P, ml, maxBranch, skip, opt_.memType, opt_.maxSmemMemStart, editDist, rp, &matches, &regF, &stF});
             if (!opt_.noRC) hot_.submit_seed_regions(SeedRegionReq{&Prc, ml, maxBranch, skip, opt_.memType, opt_.maxSmemMemStart, editDist, rp, &matchesRC, &regR, &stR});
@@ -377,6 +377,7 @@ void Mapper::cand_regions(const Read& read, std::vector<Lis>& lis, double errorP
                     Lis& l = lis.back();
                     l.fw = fw; l.refBegin = r.refBegin; l.refEnd = r.refEnd; l.score = r.score;
                     l.matches.swap(r.matches);
+                    l.chain0.swap(r.chain); l.chain0Anchor = r.chainAnchor; l.chain0Edit = r.chainEdit; l.chain0Coverage = r.chainCoverage;
                 }
             };
             take(matches, regF, stF, true);
@@ -530,7 +531,7 @@ void Mapper::right_ext(const std::string& P, int& tmpQE, int64_t& tmpRE, int64_t
 
 // extendAlignmentChain src/mapper.cpp:869-1081
 int Mapper::extend_chain(const std::string& P, const std::vector<Match>& matches, int editDist, int minScore, int minCoverage,
-                         int64_t chrStart, int64_t chrEnd, Read& read, bool fw) {
+                         int64_t chrStart, int64_t chrEnd, Read& read, bool fw, const Lis* first) {
     const char* S = idx_.S();
     int maxAlnScore = std::min(-1, minScore - 10);
     std::list<size_t> chain;
@@ -566,7 +567,15 @@ int Mapper::extend_chain(const std::string& P, const std::vector<Match>& matches
         }
         if (!extend) continue;
         int curScore = 0;
-        int minEdit = next_chain(matches, chain, anchorPos, opt_.errorPercent, used, P.length(), curScore);
+        int minEdit;
+        if (first && !first->chain0.empty() && i == (int)seedOrder.size() - 1 && (size_t)first->chain0Anchor == anchorPos) {
+            // the first chain came with the region (regions_kernel): same members, same order, nextChain's outputs
+            chain.clear();
+            for (int32_t k : first->chain0) { chain.push_back((size_t)k); if ((size_t)k != anchorPos) used[(size_t)k] = true; }
+            curScore = first->chain0Coverage;
+            minEdit = first->chain0Edit;
+        } else
+            minEdit = next_chain(matches, chain, anchorPos, opt_.errorPercent, used, P.length(), curScore);
         if (!(minEdit <= editDist && (chain.size() > 1 || anchor.len >= minCoverage))) continue;
         std::list<size_t>::const_iterator it = chain.begin(), itEnd = chain.end();
         int bandSize = std::min(opt_.fixedBandSize, (int)(editDist - minEdit + 1));
@@ -683,7 +692,7 @@ void Mapper::process_lis(Read& read, const std::vector<Lis>& lis, int editDist, 
             int64_t chrStart, chrEnd;
             idx_.chrom_bounds(cluster.matches[0].ref, chrStart, chrEnd);
             int ret = extend_chain(cluster.fw ? read.sequence : read.rcSequence, cluster.matches, editDist, minScore, minCoverage, chrStart,
-                                   chrEnd, read, cluster.fw);
+                                   chrEnd, read, cluster.fw, &cluster);
             if (cluster.fw) trialF++; else trialR++;
             if (ret >= 0 && (!opt_.maxTrialBest || maxAlnScore < ret)) {
                 if (cluster.fw) trialF = 0; else trialR = 0;

@@ -118,6 +118,8 @@ class Mapper {
    private:
     struct Lis {                  // lis_t src/mapper.h:42-65
         int score = 0; bool fw = true; int64_t refBegin = 0, refEnd = 0; bool extended = false; std::vector<Match> matches;
+        // --device-regions: the chain extendChain builds first, computed with the region (empty: not provided)
+        std::vector<int32_t> chain0; int chain0Anchor = -1, chain0Edit = 0, chain0Coverage = 0;
     };
     void unpaired_match(Read& read);
     void seeds_both_strands(const std::string& P, const std::string& Prc, int min_len, std::vector<Match>& fw, std::vector<Match>& rc);
@@ -125,7 +127,7 @@ class Mapper {
     void cand_regions(const Read& read, std::vector<Lis>& lis, double errorPercent);
     void process_lis(Read& read, const std::vector<Lis>& lis, int editDist, int maxAlnCount, int minCoverage, int minScore);
     int extend_chain(const std::string& P, const std::vector<Match>& matches, int editDist, int minScore, int minCoverage,
-                     int64_t chrStart, int64_t chrEnd, Read& read, bool fw);
+                     int64_t chrStart, int64_t chrEnd, Read& read, bool fw, const Lis* first = nullptr);
     void left_ext(const std::string& P, int& tmpQB, int64_t& tmpRB, int64_t chrStart, int& curScore, int bandSize, int editDist);
     void right_ext(const std::string& P, int& tmpQE, int64_t& tmpRE, int64_t chrEnd, int& curScore, int bandSize, int editDist);
     void postprocess(Read& read, bool paired);

@@ -3,6 +3,8 @@
 //   identifyAndFilter  src/mapper.cpp:578-704   sort (query asc, len desc) :586, SMEM triage :618-627, sort (ref, query),
 //                                              window building and merging :644-676, reserves by a two-pointer sweep :690-700
 //   coveredBases       src/mapper.cpp:706-719   per region: sort (query, ref), union of the query intervals
+//   nextChain          src/mapper.cpp:721-782   the chain extendChain builds first in a region: from its longest member (the
+//                                              anchor tried first, :885-893) forwards and backwards over the sorted members
 // so that the host receives regions (bounds, score, members in their final order) instead of rebuilding them per read.
 //
 // The sequential parts of the reference (triage, window loop, sweeps) are short scans over a few dozen matches: they run on
@@ -38,6 +40,7 @@ struct Lds {
 __global__ __launch_bounds__(64) void regions_kernel(const alfa_match* __restrict__ m_all, const int64_t* __restrict__ base,
                                                     const int32_t* __restrict__ qlen, const int32_t* __restrict__ edit, int nq,
                                                     RegionParams rp, alfa_region* __restrict__ reg_out, alfa_match* __restrict__ rm_out,
+                                                    int32_t* __restrict__ chain_out,
                                                     int32_t* __restrict__ nreg_out, int32_t* __restrict__ nrm_out, int32_t* __restrict__ status) {
     __shared__ Lds s;
     const int qi = blockIdx.x, lane = threadIdx.x;
@@ -215,8 +218,60 @@ __global__ __launch_bounds__(64) void regions_kernel(const alfa_match* __restric
                 prevEnd = stop;
                 trueCover += stop - start + 1 > 0 ? stop - start + 1 : 0;
             }
+            // ---- nextChain from the anchor extendChain tries first: the longest member, the later one among equals
+            int anchor = 0;
+            for (int k = 1; k < m; ++k) if (s.L[s.tmp[k]] >= s.L[s.tmp[anchor]]) anchor = k;
+            const int64_t MAX_OVERLAP = -10;
+            int curEdit = 0, coverage = s.L[s.tmp[anchor]];
+            int nback = 0, nfwd = 0;
+            uint16_t* back = s.o1;                      // scratch: the first sort's order is no longer needed
+            uint16_t* fwd = s.o1 + RCAP / 2;
+            const int64_t aR = s.R[s.tmp[anchor]], aQ = s.Q[s.tmp[anchor]], aL = s.L[s.tmp[anchor]];
+            int64_t refLB = aR, qLB = aQ, refRB = aR + aL - 1, qRB = aQ + aL - 1;
+            for (int k = anchor + 1; k < m; ++k) {
+                const int i = s.tmp[k];
+                const int64_t mq = s.Q[i], mr = s.R[i], ml = s.L[i];
+                const int64_t qDist = mq - (qRB + 1), refDist = mr - (refRB + 1);
+                const int64_t qLong = mq + ml - qLB, rLong = mr + ml - refLB;
+                const int64_t dd = qDist - refDist < 0 ? refDist - qDist : qDist - refDist;
+                if (qDist >= MAX_OVERLAP && refDist >= MAX_OVERLAP && dd <= (int64_t)(rp.error_percent * (double)(qLong > rLong ? qLong : rLong))) {
+                    if (nfwd < RCAP / 2) fwd[nfwd] = (uint16_t)k;
+                    nfwd++;
+                    curEdit += (int)(dd > 1 ? dd : 1);
+                    refLB = mr; refRB = mr + ml - 1; qLB = mq; qRB = mq + ml - 1;
+                    const int64_t mn = qDist < refDist ? qDist : refDist;
+                    coverage += mn < 0 ? (int)(ml + mn) : (int)ml;
+                }
+            }
+            curEdit += (int)(qRB + 1) < qLength ? 1 : 0;
+            refLB = aR; qLB = aQ; refRB = aR + aL - 1; qRB = aQ + aL - 1;
+            for (int k = anchor - 1; k >= 0; --k) {
+                const int i = s.tmp[k];
+                const int64_t mq = s.Q[i], mr = s.R[i], ml = s.L[i];
+                const int64_t qDist = qLB - (mq + ml), refDist = refLB - (mr + ml);
+                const int64_t qLong = qRB - mq + 1, rLong = refRB - mr + 1;
+                const int64_t dd = qDist - refDist < 0 ? refDist - qDist : qDist - refDist;
+                if (qDist >= MAX_OVERLAP && refDist >= MAX_OVERLAP && dd <= (int64_t)(rp.error_percent * (double)(qLong > rLong ? qLong : rLong))) {
+                    if (nback < RCAP / 2) back[nback] = (uint16_t)k;
+                    nback++;
+                    curEdit += (int)(dd > 1 ? dd : 1);
+                    refLB = mr; refRB = mr + ml - 1; qLB = mq; qRB = mq + ml - 1;
+                    const int64_t mn = qDist < refDist ? qDist : refDist;
+                    coverage += mn < 0 ? (int)(ml + mn) : (int)ml;
+                }
+            }
+            curEdit += qLB > 0 ? 1 : 0;
+            if (nback > RCAP / 2 || nfwd > RCAP / 2) s.fail = 1;
+            else {
+                int32_t* co = chain_out + rm_base + cursor;
+                int c = 0;
+                for (int k = nback - 1; k >= 0; --k) co[c++] = back[k];
+                co[c++] = anchor;
+                for (int k = 0; k < nfwd; ++k) co[c++] = fwd[k];
+            }
             alfa_region o;
-            o.ref_begin = s.rb[r]; o.ref_end = s.re[r]; o.score = trueCover; o.first = cursor; o.count = m; o.reserved = 0;
+            o.ref_begin = s.rb[r]; o.ref_end = s.re[r]; o.score = trueCover; o.first = cursor; o.count = m;
+            o.chain_count = nback + 1 + nfwd; o.chain_anchor = anchor; o.chain_edit = curEdit; o.chain_coverage = coverage; o.reserved = 0;
             reg_out[b0 + r] = o;
         }
         cursor += m;
@@ -231,9 +286,9 @@ __global__ __launch_bounds__(64) void regions_kernel(const alfa_match* __restric
 }
 
 void launch_regions(hipStream_t st, const alfa_match* d_m, const int64_t* d_base, const int32_t* d_qlen, const int32_t* d_edit, int nq,
-                    const RegionParams& rp, alfa_region* d_reg, alfa_match* d_rm, int32_t* d_nreg, int32_t* d_nrm, int32_t* d_status) {
+                    const RegionParams& rp, alfa_region* d_reg, alfa_match* d_rm, int32_t* d_chain, int32_t* d_nreg, int32_t* d_nrm, int32_t* d_status) {
     if (nq <= 0) return;
-    hipLaunchKernelGGL(regions_kernel, dim3(nq), dim3(64), 0, st, d_m, d_base, d_qlen, d_edit, nq, rp, d_reg, d_rm, d_nreg, d_nrm, d_status);
+    hipLaunchKernelGGL(regions_kernel, dim3(nq), dim3(64), 0, st, d_m, d_base, d_qlen, d_edit, nq, rp, d_reg, d_rm, d_chain, d_nreg, d_nrm, d_status);
 }
 
 }  // namespace alfa

@@ -1773,7 +1773,7 @@ struct alfa_seed_plan {
     int stride = 0;              // persistent kernel: LDS bytes per wave for its read
     int64_t out_cap = 0;
     alfa::DevBuf d_reads, d_q, d_tot, d_base, d_work, d_cnt, d_out, d_tmp, d_scr, d_q3;
-    alfa::DevBuf d_reg, d_rm, d_aux;     // alfa_seed_regions_batch: regions, their members, per-strand ints
+    alfa::DevBuf d_reg, d_rm, d_chain, d_aux;     // alfa_seed_regions_batch: regions, their members, first chains, per-strand ints
     size_t tmp_bytes = 0;
     int mem_type = ALFA_SEED_SMAM;
     size_t work_rec = sizeof(WorkRec);
@@ -2064,7 +2064,7 @@ int plan_fetch(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_match** matches, int64_t*
 void plan_release(alfa_seed_plan* pl) {
     pl->d_reads.release(); pl->d_q.release(); pl->d_tot.release(); pl->d_base.release(); pl->d_work.release(); pl->d_out.release();
     pl->d_tmp.release(); pl->d_scr.release(); pl->d_cnt.release(); pl->d_q3.release();
-    pl->d_reg.release(); pl->d_rm.release(); pl->d_aux.release();
+    pl->d_reg.release(); pl->d_rm.release(); pl->d_chain.release(); pl->d_aux.release();
     for (alfa::DevBuf* b : {&pl->d_qbase, &pl->d_keys, &pl->d_keys2, &pl->d_vals, &pl->d_vals2, &pl->d_fcnt, &pl->d_fscan, &pl->d_frec, &pl->d_sorttmp}) b->release();
     if (pl->ev0) { (void)hipEventDestroy(pl->ev0); (void)hipEventDestroy(pl->ev1); pl->ev0 = pl->ev1 = nullptr; }
 }
@@ -2149,26 +2149,27 @@ int alfa_seed_batch(alfa_index* ix, int mem_type, const alfa_seed_query* q, int 
 // seeds, then identifyAndFilter + coveredBases on the matches where they lie (region_kernels.hip); see include/alfa_hot.h
 int alfa_seed_regions_batch(alfa_index* ix, int mem_type, const alfa_seed_query* q, const int32_t* edit_dist, int nq, const alfa_region_params* p,
                             alfa_match** matches, int64_t* match_off, alfa_region** regions, int64_t* region_off, alfa_match** members,
-                            int64_t* member_off, int32_t* status) {
+                            int64_t* member_off, int32_t** chains, int32_t* status) {
     alfa::g_last_timing = alfa::Timing();
-    if (!ix || !p || !matches || !match_off || !regions || !region_off || !members || !member_off || nq < 0 ||
+    if (!ix || !p || !matches || !match_off || !regions || !region_off || !members || !member_off || !chains || nq < 0 ||
         (nq > 0 && (!q || !edit_dist || !status)))
         return alfa::fail(ALFA_EINVAL, "null argument");
     alfa::Ctx* cx = alfa::thread_ctx(ix->device);
     if (!cx) return ALFA_ENODEV;
     alfa_seed_plan* pl = thread_plan(1);
     int rc;
-    *matches = nullptr; *regions = nullptr; *members = nullptr;
+    *matches = nullptr; *regions = nullptr; *members = nullptr; *chains = nullptr;
     if ((rc = plan_fill(pl, cx, ix, mem_type, q, nq)) || (rc = plan_launch(pl, cx)) || (rc = plan_fetch(pl, cx, matches, match_off))) return rc;
     region_off[0] = member_off[0] = 0;
     *regions = (alfa_region*)malloc(sizeof(alfa_region));
     *members = (alfa_match*)malloc(sizeof(alfa_match));
-    if (!*regions || !*members) return alfa::fail(ALFA_ENOMEM, "out of host memory");
+    *chains = (int32_t*)malloc(sizeof(int32_t));
+    if (!*regions || !*members || !*chains) return alfa::fail(ALFA_ENOMEM, "out of host memory");
     if (nq == 0) return ALFA_OK;
     const int64_t total = match_off[nq];
     const size_t rm_slots = 2 * (size_t)total + 8 * (size_t)nq;
     hipStream_t st = cx->stream;
-    if ((rc = pl->d_reg.reserve(sizeof(alfa_region) * (size_t)(total + 1))) || (rc = pl->d_rm.reserve(sizeof(alfa_match) * (rm_slots + 1))) ||
+    if ((rc = pl->d_reg.reserve(sizeof(alfa_region) * (size_t)(total + 1))) || (rc = pl->d_rm.reserve(sizeof(alfa_match) * (rm_slots + 1))) || (rc = pl->d_chain.reserve(4 * (rm_slots + 1))) ||
         (rc = pl->d_aux.reserve(4 * 5 * (size_t)nq + 64)) || (rc = cx->h_tasks.reserve(4 * 5 * (size_t)nq + 64)))
         return rc;
     int32_t* h_aux = cx->h_tasks.as<int32_t>();                 // [qlen | edit | nreg | nrm | status]
@@ -2179,8 +2180,9 @@ int alfa_seed_regions_batch(alfa_index* ix, int mem_type, const alfa_seed_query*
     rp.max_smem_occ = p->max_seed_candidates < 0 ? INT64_MAX : p->max_seed_candidates;      // the reference holds them in size_t
     rp.max_region_mems = p->max_region_mems < 0 ? INT64_MAX : p->max_region_mems;
     rp.min_mem_reg_length = p->min_mem_reg_length;
+    rp.error_percent = p->error_percent;
     alfa::launch_regions(st, pl->d_out.as<alfa_match>(), pl->d_base.as<int64_t>(), d_aux, d_aux + nq, nq, rp, pl->d_reg.as<alfa_region>(),
-                         pl->d_rm.as<alfa_match>(), d_aux + 2 * (size_t)nq, d_aux + 3 * (size_t)nq, d_aux + 4 * (size_t)nq);
+                         pl->d_rm.as<alfa_match>(), pl->d_chain.as<int32_t>(), d_aux + 2 * (size_t)nq, d_aux + 3 * (size_t)nq, d_aux + 4 * (size_t)nq);
     ALFA_HIP(hipGetLastError());
     ALFA_HIP(hipMemcpyAsync(h_aux + 2 * (size_t)nq, d_aux + 2 * (size_t)nq, 4 * 3 * (size_t)nq, hipMemcpyDeviceToHost, st));
     ALFA_HIP(hipStreamSynchronize(st));
@@ -2195,20 +2197,25 @@ int alfa_seed_regions_batch(alfa_index* ix, int mem_type, const alfa_seed_query*
     // the device arrays are slotted per strand (worst-case sizes); they come back whole and are compacted here
     alfa_region* hr_all = (alfa_region*)malloc(sizeof(alfa_region) * (size_t)(total + 1));
     alfa_match* hm_all = (alfa_match*)malloc(sizeof(alfa_match) * (rm_slots + 1));
+    int32_t* hc_all = (int32_t*)malloc(4 * (rm_slots + 1));
+    int32_t* hc = (int32_t*)realloc(*chains, 4 * (size_t)(nrm_total + 1));
+    if (hc) *chains = hc;
     alfa_region* hr = (alfa_region*)realloc(*regions, sizeof(alfa_region) * (size_t)(nreg_total + 1));
     alfa_match* hm = (alfa_match*)realloc(*members, sizeof(alfa_match) * (size_t)(nrm_total + 1));
     if (hr) *regions = hr;
     if (hm) *members = hm;
-    if (!hr_all || !hm_all || !hr || !hm) { free(hr_all); free(hm_all); return alfa::fail(ALFA_ENOMEM, "out of host memory for the region arrays"); }
+    if (!hr_all || !hm_all || !hc_all || !hr || !hm || !hc) { free(hr_all); free(hm_all); free(hc_all); return alfa::fail(ALFA_ENOMEM, "out of host memory for the region arrays"); }
     hipError_t e = hipMemcpyAsync(hr_all, pl->d_reg.p, sizeof(alfa_region) * (size_t)total, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(hm_all, pl->d_rm.p, sizeof(alfa_match) * rm_slots, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(hc_all, pl->d_chain.p, 4 * rm_slots, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { free(hr_all); free(hm_all); return alfa::fail(ALFA_EHIP, hipGetErrorString(e)); }
+    if (e != hipSuccess) { free(hr_all); free(hm_all); free(hc_all); return alfa::fail(ALFA_EHIP, hipGetErrorString(e)); }
     for (int i = 0; i < nq; ++i) {
         if (h_nreg[i] > 0) memcpy(hr + region_off[i], hr_all + match_off[i], sizeof(alfa_region) * (size_t)h_nreg[i]);
         if (h_nrm[i] > 0) memcpy(hm + member_off[i], hm_all + 2 * match_off[i] + 8 * (int64_t)i, sizeof(alfa_match) * (size_t)h_nrm[i]);
+        if (h_nrm[i] > 0) memcpy(hc + member_off[i], hc_all + 2 * match_off[i] + 8 * (int64_t)i, 4 * (size_t)h_nrm[i]);
     }
-    free(hr_all); free(hm_all);
+    free(hr_all); free(hm_all); free(hc_all);
     alfa::g_last_timing.kernel_ms = alfa_seed_plan_kernel_ms(pl);
     alfa::g_last_timing.work_units = pl->total_pref;
     alfa::g_last_timing.launches = 1;

@@ -34,11 +34,13 @@ class Match(C.Structure):
 MATCH_DTYPE = np.dtype([("ref", "<i8"), ("query", "<i4"), ("len", "<i4")])
 
 
-REGION_DTYPE = np.dtype([("ref_begin", "<i8"), ("ref_end", "<i8"), ("score", "<i4"), ("first", "<i4"), ("count", "<i4"), ("reserved", "<i4")])
+REGION_DTYPE = np.dtype([("ref_begin", "<i8"), ("ref_end", "<i8"), ("score", "<i4"), ("first", "<i4"), ("count", "<i4"), ("chain_count", "<i4"),
+                         ("chain_anchor", "<i4"), ("chain_edit", "<i4"), ("chain_coverage", "<i4"), ("reserved", "<i4")])
 
 
 class RegionParams(C.Structure):
-    _fields_ = [("max_seed_candidates", C.c_int32), ("max_region_mems", C.c_int32), ("min_mem_reg_length", C.c_int32)]
+    _fields_ = [("max_seed_candidates", C.c_int32), ("max_region_mems", C.c_int32), ("min_mem_reg_length", C.c_int32),
+                ("reserved", C.c_int32), ("error_percent", C.c_double)]
 
 
 class SeedQuery(C.Structure):
@@ -304,25 +306,27 @@ class DeviceIndex:
             return rc
         return _seed_call(fn, self._h, mem_type, queries, lib().alfa_free)
 
-    def seed_regions_batch(self, mem_type, queries, edit_dist, max_seed_candidates=10000, max_region_mems=20, min_mem_reg_length=50):
-        """alfa_seed_regions_batch: (matches, match_off, regions, region_off, members, member_off, status)"""
+    def seed_regions_batch(self, mem_type, queries, edit_dist, max_seed_candidates=10000, max_region_mems=20, min_mem_reg_length=50,
+                           error_percent=0.08):
+        """alfa_seed_regions_batch: (matches, match_off, regions, region_off, members, member_off, status, chains)"""
         nq = len(queries)
         ed = np.ascontiguousarray(edit_dist, dtype=np.int32)
-        prm = RegionParams(int(max_seed_candidates), int(max_region_mems), int(min_mem_reg_length))
-        m, r, mb = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        prm = RegionParams(int(max_seed_candidates), int(max_region_mems), int(min_mem_reg_length), 0, float(error_percent))
+        m, r, mb, ch = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         moff, roff, boff = (np.zeros(nq + 1, dtype=np.int64) for _ in range(3))
         status = np.zeros(max(nq, 1), dtype=np.int32)
         L = lib()
-        L.alfa_seed_regions_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 7
+        L.alfa_seed_regions_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 8
         check(L.alfa_seed_regions_batch(self._h, int(mem_type), C.cast(queries, C.c_void_p), ed.ctypes.data_as(C.c_void_p), nq, C.byref(prm),
                                         C.byref(m), moff.ctypes.data_as(C.c_void_p), C.byref(r), roff.ctypes.data_as(C.c_void_p),
-                                        C.byref(mb), boff.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p)))
+                                        C.byref(mb), boff.ctypes.data_as(C.c_void_p), C.byref(ch), status.ctypes.data_as(C.c_void_p)))
 
         def take(ptr, count, dt):
             out = np.frombuffer(C.string_at(ptr.value, int(count) * dt.itemsize), dtype=dt).copy() if count else np.zeros(0, dtype=dt)
             L.alfa_free(ptr)
             return out
-        return (take(m, moff[nq], MATCH_DTYPE), moff, take(r, roff[nq], REGION_DTYPE), roff, take(mb, boff[nq], MATCH_DTYPE), boff, status[:nq])
+        return (take(m, moff[nq], MATCH_DTYPE), moff, take(r, roff[nq], REGION_DTYPE), roff, take(mb, boff[nq], MATCH_DTYPE), boff, status[:nq],
+                take(ch, boff[nq], np.dtype("<i4")))
 
     def __del__(self):
         try:

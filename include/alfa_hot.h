@@ -127,13 +127,22 @@ int  alfa_seed_batch(alfa_index*, int mem_type, const alfa_seed_query* q, int nq
  *                   them; region r owns (*members)[member_off[i] + r.first .. + r.count), sorted as coveredBases leaves them
  *   status[i] == 1: the strand is left to the caller (more matches or regions than the kernel holds, or matches that compare
  *                   equal under the reference's comparators but differ: std::sort's order of those cannot be reproduced)
- * match_off, region_off, member_off have nq+1 entries, status nq (caller-allocated); the three arrays are library-allocated
- * (alfa_free).  p: maxSeedCandidates, maxRegionMems, minMemRegLength (alnOptions, src/options.h). */
-typedef struct { int64_t ref_begin, ref_end; int32_t score, first, count, reserved; } alfa_region;
-typedef struct { int32_t max_seed_candidates, max_region_mems, min_mem_reg_length; } alfa_region_params;
+ * match_off, region_off, member_off have nq+1 entries, status nq (caller-allocated); the four arrays are library-allocated
+ * (alfa_free); *chains runs parallel to *members.  p: maxSeedCandidates, maxRegionMems, minMemRegLength, errorPercent (alnOptions,
+ * src/options.h). */
+typedef struct {
+    int64_t ref_begin, ref_end;
+    int32_t score, first, count;
+    /* the chain extendChain builds first in this region (nextChain src/mapper.cpp:721-782 from the anchor it tries first, the
+     * longest member, :885-893): member indices (*chains)[member_off[i] + first .. + chain_count) in chain order, its edit
+     * estimate (nextChain's return value) and coverage; chain_anchor = the anchor's member index */
+    int32_t chain_count, chain_anchor, chain_edit, chain_coverage, reserved;
+} alfa_region;
+typedef struct { int32_t max_seed_candidates, max_region_mems, min_mem_reg_length; int32_t reserved; double error_percent; } alfa_region_params;
 int  alfa_seed_regions_batch(alfa_index*, int mem_type, const alfa_seed_query* q, const int32_t* edit_dist, int nq,
                              const alfa_region_params* p, alfa_match** matches, int64_t* match_off,
-                             alfa_region** regions, int64_t* region_off, alfa_match** members, int64_t* member_off, int32_t* status);
+                             alfa_region** regions, int64_t* region_off, alfa_match** members, int64_t* member_off, int32_t** chains,
+                             int32_t* status);
 
 /* --- banded DP ---------------------------------------------------------- */
 /* replaces: ksw_extend(...)  src/ksw.h:106 / src/ksw.c:362 */

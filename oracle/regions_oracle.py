@@ -98,3 +98,36 @@ def covered_bases(members):
         prev_end = stop
         cover += max(0, stop - start + 1)
     return cover, amb
+
+
+def first_chain(members, q_length, error_percent):
+    """nextChain  /root/reference/src/mapper.cpp:721-782 from the anchor extendChain tries first (:885-893: ascending
+    (len << 32 | index), taken from the back).  members as covered_bases leaves them.  Returns (chain, anchor, edit, coverage)."""
+    MAX_OVERLAP = -10
+    anchor = max(range(len(members)), key=lambda k: (members[k][2], k))
+    a = members[anchor]
+    cur_edit, coverage = 0, a[2]
+    fwd, back = [], []
+    ref_lb, q_lb, ref_rb, q_rb = a[0], a[1], a[0] + a[2] - 1, a[1] + a[2] - 1
+    for k in range(anchor + 1, len(members)):
+        mr, mq, ml = members[k]
+        q_dist, ref_dist = mq - (q_rb + 1), mr - (ref_rb + 1)
+        q_long, r_long = mq + ml - q_lb, mr + ml - ref_lb
+        if q_dist >= MAX_OVERLAP and ref_dist >= MAX_OVERLAP and abs(q_dist - ref_dist) <= int(error_percent * float(max(q_long, r_long))):
+            fwd.append(k)
+            cur_edit += max(1, abs(q_dist - ref_dist))
+            ref_lb, ref_rb, q_lb, q_rb = mr, mr + ml - 1, mq, mq + ml - 1
+            coverage += ml + min(q_dist, ref_dist) if min(q_dist, ref_dist) < 0 else ml
+    cur_edit += 1 if q_rb + 1 < q_length else 0
+    ref_lb, q_lb, ref_rb, q_rb = a[0], a[1], a[0] + a[2] - 1, a[1] + a[2] - 1
+    for k in range(anchor - 1, -1, -1):
+        mr, mq, ml = members[k]
+        q_dist, ref_dist = q_lb - (mq + ml), ref_lb - (mr + ml)
+        q_long, r_long = q_rb - mq + 1, ref_rb - mr + 1
+        if q_dist >= MAX_OVERLAP and ref_dist >= MAX_OVERLAP and abs(q_dist - ref_dist) <= int(error_percent * float(max(q_long, r_long))):
+            back.append(k)
+            cur_edit += max(1, abs(q_dist - ref_dist))
+            ref_lb, ref_rb, q_lb, q_rb = mr, mr + ml - 1, mq, mq + ml - 1
+            coverage += ml + min(q_dist, ref_dist) if min(q_dist, ref_dist) < 0 else ml
+    cur_edit += 1 if q_lb > 0 else 0
+    return back[::-1] + [anchor] + fwd, anchor, cur_edit, coverage

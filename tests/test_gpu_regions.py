@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 
 def _check(dix, reads, min_len, sparse_q, edit, **prm):
     q = ffi.make_seed_queries(reads, min_len, 10000, sparse_q)
-    m, moff, reg, roff, mem, boff, status = dix.seed_regions_batch(ffi.SEED_SMAM, q, edit, **prm)
+    m, moff, reg, roff, mem, boff, status, chains = dix.seed_regions_batch(ffi.SEED_SMAM, q, edit, **prm)
+    err = prm.get("error_percent", 0.08)
     m2, moff2 = dix.seed_batch(ffi.SEED_SMAM, q)
     assert np.array_equal(moff, moff2) and np.array_equal(m, m2)
     ndev = 0
@@ -45,6 +46,9 @@ def _check(dix, reads, min_len, sparse_q, edit, **prm):
             assert (int(g["ref_begin"]), int(g["ref_end"]), int(g["score"]), int(g["count"])) == (e[0], e[1], sc, len(e[2])), (i, g, e[:2], sc)
             mm = mem[boff[i] + g["first"]:boff[i] + g["first"] + g["count"]]
             assert [(int(x["ref"]), int(x["query"]), int(x["len"])) for x in mm] == e[2], i
+            chain, anchor, ced, ccov = RO.first_chain(e[2], len(r), err)
+            got_chain = chains[boff[i] + g["first"]:boff[i] + g["first"] + g["chain_count"]].tolist()
+            assert (got_chain, int(g["chain_anchor"]), int(g["chain_edit"]), int(g["chain_coverage"])) == (chain, anchor, ced, ccov), (i, got_chain, chain)
     return ndev
 
 
@@ -58,7 +62,7 @@ def test_regions_random_reference(gpu):
     edit = np.array([int(0.08 * len(r)) + 1 for r in reads], np.int32)
     n = _check(dix, reads, 20, 1, edit)
     assert n > 1400
-    _check(dix, reads, 40, 2, edit, max_seed_candidates=3, max_region_mems=2, min_mem_reg_length=30)
+    _check(dix, reads, 40, 2, edit, max_seed_candidates=3, max_region_mems=2, min_mem_reg_length=30, error_percent=0.21)
 
 
 def test_regions_repeats(gpu):
