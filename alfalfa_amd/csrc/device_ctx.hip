@@ -1,10 +1,29 @@
 // device_ctx.hip -- see device_ctx.h
 #include "device_ctx.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <vector>
+
+// Hardware queues.  A DP call forks its kernel bins onto side streams (ksw_kernels.hip: launch_all) and a mapper thread adds
+// its seed and upload streams; HIP multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (4 unless the
+// variable says otherwise), and streams that share a queue run one after the other.  Measured on the C4 stream
+// (tools/gpu_queue_ab.sh): 12.5 ms per step with 4 queues, 10.7 with 8, 7.9 with 16, 8.1-8.2 with 24-32; the C3 step is
+// unchanged (0.58-0.59 ms).  The library therefore sets GPU_MAX_HW_QUEUES to ALFA_HW_QUEUES (default 16, at most 32) when it
+// is loaded; ALFA_HW_QUEUES=0 leaves the variable alone.  The HIP runtime reads it when it initialises (its first call), so
+// a host that has used HIP before loading the library keeps whatever it had.
+__attribute__((constructor)) static void alfa_default_hw_queues() {
+    const char* e = getenv("ALFA_HW_QUEUES");
+    int n = e ? atoi(e) : 16;
+    if (n <= 0) return;
+    if (n > 32) n = 32;
+    char buf[8];
+    snprintf(buf, sizeof buf, "%d", n);
+    (void)setenv("GPU_MAX_HW_QUEUES", buf, 1);
+}
 
 namespace alfa {
 

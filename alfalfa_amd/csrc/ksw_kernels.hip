@@ -59,6 +59,7 @@ struct DevTask {
 struct DevParams {
     uint64_t matrow[8];   // matrow[t] byte q = mat[t*m+q]
     int32_t m, gapo, gape, zdrop;
+    int32_t maxs, pad_;   // largest matrix entry (>= 0): bounds a task's scores by h0 + qlen * maxs
 };
 
 struct ExtOut { int32_t score, qle, tle, gtle, gscore, max_off; };
@@ -104,23 +105,38 @@ __device__ __forceinline__ int score_of(uint64_t mr, uint32_t q) { return (int)(
 // the same with the residue kept as its shift amount (8 x code): the band kernels carry query residues in that form
 __device__ __forceinline__ int score_at(uint64_t mr, uint32_t q8) { return (int)(int8_t)(mr >> q8); }
 
+// A launch is ordered longest task first and ends when its longest task does: a wavefront's rows are a serial chain of a few
+// hundred instructions each, so a 10 000-row task takes milliseconds even with a SIMD to itself, and several times that
+// when it shares the SIMD's issue slots evenly with three shorter neighbours.  The first wavefronts of a launch therefore
+// raise their issue priority (s_setprio): the long chains run at nearly their solo speed and the rest fills the gaps.
+__device__ __forceinline__ void rank_priority(int wave_rank) {
+    if (wave_rank < 1024) __builtin_amdgcn_s_setprio(3);
+    else if (wave_rank < 3072) __builtin_amdgcn_s_setprio(1);
+}
+
 // ---------------------------------------------------------------- wave-per-task kernel
 // one task on the 64 lanes of the calling wavefront (bands of up to 64 x C diagonals); all lanes call it together
-template <int MODE, int C>
+// PACK (ksw_extend): the row maximum and its last column come out of one reduction over (H << 8 | diagonal); the caller
+// passes true only when the task's scores stay below 2^22 (every H <= h0 + qlen * maxs: wave_task_packs)
+template <int MODE, int C, bool PACK = false>
 __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __restrict__ seq, const DevParams* __restrict__ prm,
                                           int32_t* __restrict__ out, uint8_t* __restrict__ zbuf) {
     const int lane = lane_id();
-    const uint8_t* __restrict__ q = seq + T.qoff;
-    const uint8_t* __restrict__ tg = seq + T.toff;
-    const int qlen = T.qlen, tlen = T.tlen, w = T.w;
+    // the task is the same for all 64 lanes: its fields in scalar registers make the row loop and its bounds wave-uniform
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uni64 = [&](int64_t v) { return (int64_t)(((uint64_t)(uint32_t)uni((int)((uint64_t)v >> 32)) << 32) | (uint32_t)uni((int)v)); };
+    const uint8_t* __restrict__ q = seq + uni64(T.qoff);
+    const uint8_t* __restrict__ tg = seq + uni64(T.toff);
+    const int qlen = uni(T.qlen), tlen = uni(T.tlen), w = uni(T.w);
     const int gapo = prm->gapo, gape = prm->gape, gapoe = gapo + gape;
     const int zdrop = prm->zdrop;
     constexpr int FLOOR = (MODE == MODE_EXTEND) ? 0 : NEG_INF;
     constexpr int ROWB = 64 * C;  // direction bytes per row
+    uint8_t* const zrow0 = MODE == MODE_GLOBAL ? zbuf + uni64(T.zoff) : nullptr;
 
     int Hd[C], E[C];
     uint32_t qc[C];
-    int h0 = T.h0;
+    int h0 = uni(T.h0);
     if (MODE == MODE_EXTEND && h0 < 0) h0 = 0;
     const int eh1 = h0 > gapoe ? h0 - gapoe : 0;
 #pragma unroll
@@ -145,13 +161,21 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
         }
     }
 
+    // ksw_nw / ksw_global: the band is static in diagonal coordinates, so no cell needs a per-row mask.  Cells left of column
+    // 0 start at MINUS_INF and stay hugely negative (they only see each other, a score per row and the exact first-column value
+    // that is injected below), cells right of the query's end or beyond diagonal 2w hold junk that only flows rightwards
+    // (every dependency of (i,j) has a column <= j), and the one value that crosses back into the band -- E of diagonal
+    // 2w+1, read by diagonal 2w one row later -- is pinned to MINUS_INF, which is what the reference's untouched eh[j].e holds
+    constexpr bool STATIC_BAND = MODE != MODE_EXTEND;
+    bool dead[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) dead[c] = lane * C + c == 2 * w + 1;
     int beg = 0, end = qlen;                                    // EXTEND state
     int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
     // the row's target residue and the query residue that enters the top diagonal come out of 8-byte windows that are loaded
-    // eight rows ahead, and the matrix rows sit in registers: no row waits for a memory round trip
-    uint64_t mrow[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) mrow[k] = prm->matrow[k];
+    // eight rows ahead, and the matrix rows sit in registers (read by lane index): no row waits for a memory round trip
+    const uint64_t mat_l = prm->matrow[lane & 7];                 // lane k (k < 8) holds row k of the scoring matrix
+    const int mat_lo = (int)(uint32_t)mat_l, mat_hi = (int)(uint32_t)(mat_l >> 32);
     auto load8 = [](const uint8_t* __restrict__ p, int from, int len) -> uint64_t {      // bytes from..from+7 of p[0..len), 0 outside
         uint64_t v = 0;
         if (from >= 0 && from + 8 <= len) __builtin_memcpy(&v, p + from, 8);
@@ -164,7 +188,11 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
     uint64_t tcur = load8(tg, 0, tlen), tnxt = load8(tg, 8, tlen);
     uint64_t qcur = load8(q, xq0, qlen), qnxt = load8(q, xq0 + 8, qlen);
 
-    for (int i = 0; i < tlen; ++i) {
+    int dcol[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) dcol[c] = lane * C + c;
+    int base = -w;                       // column of diagonal 0 on row i
+    for (int i = 0; i < tlen; ++i, ++base) {
         const int ph = 8 * (i & 7);
         const int tch = __builtin_amdgcn_readfirstlane((int)((tcur >> ph) & 0xffu));
         const int xq = i + xq0;
@@ -173,28 +201,21 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
             tcur = tnxt; tnxt = load8(tg, i + 9, tlen);
             qcur = qnxt; qnxt = load8(q, xq + 9, qlen);
         }
-        uint64_t mr = mrow[0];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) mr = tch == k ? mrow[k] : mr;
+        const uint64_t mr = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mat_hi, tch) << 32) | (uint32_t)__builtin_amdgcn_readlane(mat_lo, tch);
 
         if (MODE == MODE_EXTEND) {
-            if (beg < i - w) beg = i - w;
-            if (end > i + w + 1) end = i + w + 1;
-            if (end > qlen) end = qlen;
-        } else {
-            beg = i > w ? i - w : 0;
-            end = i + w + 1 < qlen ? i + w + 1 : qlen;
+            beg = max(beg, base);
+            end = min(min(end, base + 2 * w + 1), qlen);
         }
-        const int base = i - w;          // column of diagonal 0 on this row
         const int db = beg - base, de = end - base;
+        const uint32_t dwidth = (uint32_t)max(de - db, 0);
 
         int A[C], Bv[C];
         bool act[C];
         uint32_t dirH[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const int d = lane * C + c;
-            act[c] = d >= db && d < de;
+            act[c] = STATIC_BAND || (uint32_t)(dcol[c] - db) < dwidth;
             const int hh = Hd[c] + score_at(mr, qc[c]);
             const int e = E[c];
             if (MODE == MODE_EXTEND) { A[c] = hh > e ? hh : e; dirH[c] = 0; }
@@ -212,7 +233,8 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
 
         int Hrow[C], Eo[C];
         uint32_t zpack = 0;
-        int m_l = -1, mj_l = -1;       // EXTEND: lane-local row max and its last column
+        int m_l = -1, mj_l = -1;       // EXTEND: lane-local row max and its last column (or their packed form in m_l)
+        uint32_t hmin_l = 0xffffffffu;  // EXTEND: smallest H of the lane's in-band cells
         int zl_l = -1, zr_l = 0x7fffffff;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -230,16 +252,19 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
                 dd |= (f2 > t) ? 32u : 0u;
                 zpack |= (act[c] ? dd : 0u) << (8 * c);
             }
-            Eo[c] = act[c] ? (e2 > t ? e2 : t) : FLOOR;
+            Eo[c] = (STATIC_BAND ? !dead[c] : act[c]) ? (e2 > t ? e2 : t) : FLOOR;
             const int tt = act[c] ? t : FLOOR;
             f = f2 > tt ? f2 : tt;
             if (act[c]) Hd[c] = h;
-            if (MODE == MODE_EXTEND && act[c]) {
-                if (h >= m_l) { m_l = h; mj_l = base + lane * C + c; }   // ties -> later column (ksw.c:414)
+            if (MODE == MODE_EXTEND) {
+                const int hx = act[c] ? h : -1;
+                hmin_l = min(hmin_l, (uint32_t)hx);
+                if (PACK) m_l = max(m_l, (int)(((uint32_t)hx << 8) | (uint32_t)dcol[c]));      // out of band: negative
+                else if (act[c] && h >= m_l) { m_l = h; mj_l = base + dcol[c]; }               // ties -> later column (ksw.c:414)
             }
         }
         if (MODE == MODE_GLOBAL) {
-            uint8_t* zr = zbuf + T.zoff + (int64_t)i * ROWB + lane * C;
+            uint8_t* zr = zrow0 + (int64_t)i * ROWB + lane * C;
             if (C == 4) *(uint32_t*)zr = zpack;
             else if (C == 2) *(uint16_t*)zr = (uint16_t)zpack;
             else *zr = (uint8_t)zpack;
@@ -247,22 +272,29 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
 
         if (MODE == MODE_EXTEND) {
             // ---- row maximum m and its last column mj (ksw.c:414-415)
-            const int m = wave_max(m_l);                    // -1 when the row is empty
-            const int mj = wave_max(m_l == m ? mj_l : -1);
+            int m, mj;                                      // -1 when the row is empty
+            if (PACK) {
+                const int key = wave_max(m_l);
+                m = key >> 8;
+                mj = key < 0 ? -1 : base + (key & 255);
+            } else {
+                m = wave_max(m_l);
+                mj = wave_max(m_l == m ? mj_l : -1);
+            }
             const bool empty = !(beg < end);
             const int jfin = empty ? beg : end;             // value of the loop variable after the j loop
-            int h1 = h0 - (gapo + gape * (i + 1));          // first-column value (ksw.c:395-396)
-            if (h1 < 0) h1 = 0;
-            const int h1_init = h1;
-            if (!empty) {
-                // H(i,end-1): the value the reference leaves in h1
-                const int dl = end - 1 - base;
-                int hv = Hrow[0];
-#pragma unroll
-                for (int c = 1; c < C; ++c) hv = (dl % C == c) ? Hrow[c] : hv;
-                h1 = lane_bcast(hv, dl / C);
-            }
+            int h1_init = h0 - (gapo + gape * (i + 1));     // first-column value (ksw.c:395-396)
+            if (h1_init < 0) h1_init = 0;
             if (jfin == qlen) {                             // ksw.c:425-428
+                int h1 = h1_init;
+                if (!empty) {
+                    // H(i,end-1): the value the reference leaves in h1
+                    const int dl = end - 1 - base;
+                    int hv = Hrow[0];
+#pragma unroll
+                    for (int c = 1; c < C; ++c) hv = (dl % C == c) ? Hrow[c] : hv;
+                    h1 = lane_bcast(hv, dl / C);
+                }
                 max_ie = gscore > h1 ? max_ie : i;
                 gscore = gscore > h1 ? gscore : h1;
             }
@@ -281,11 +313,8 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
             // ---- band shrink (ksw.c:435-438) in terms of this row's H values:
             //   eh[j].h == H(i,j-1) for beg<j<=end, eh[beg].h == h1_init
             // (an in-band zero is rare while the extension is alive: the two reductions run only when a lane holds one)
-            bool lane_zero = false;
-#pragma unroll
-            for (int c = 0; c < C; ++c) lane_zero |= act[c] & (Hrow[c] == 0);
             int zl = -1, zr = 0x7fffffff;
-            if (__ballot(lane_zero)) {          // wave-uniform
+            if (__ballot(hmin_l == 0)) {        // wave-uniform
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const int j = base + lane * C + c;
@@ -352,6 +381,11 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
     }
 }
 
+__device__ __forceinline__ bool wave_task_packs(const DevTask& T, const DevParams* __restrict__ prm) {
+    const int h0 = T.h0 < 0 ? 0 : T.h0;
+    return __builtin_amdgcn_readfirstlane((int64_t)h0 + (int64_t)T.qlen * prm->maxs < (1 << 22) ? 1 : 0) != 0;
+}
+
 template <int MODE, int C>
 __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __restrict__ tasks, int ntask,
                                                            const uint8_t* __restrict__ seq,
@@ -359,7 +393,10 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
                                                            int32_t* __restrict__ out, uint8_t* __restrict__ zbuf) {
     const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (wave >= ntask) return;
-    wave_task<MODE, C>(tasks[wave], seq, prm, out, zbuf);
+    rank_priority(wave);
+    const DevTask T = tasks[wave];
+    if (MODE == MODE_EXTEND && wave_task_packs(T, prm)) wave_task<MODE, C, true>(T, seq, prm, out, zbuf);
+    else wave_task<MODE, C>(T, seq, prm, out, zbuf);
 }
 
 // ---------------------------------------------------------------- group kernel: 16 lanes per task, 4 tasks per wavefront
@@ -443,6 +480,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
     __syncthreads();
     const int lane = lane_id();
     const int gl = lane & (GL - 1);
+    rank_priority(blockIdx.x * WPB + (threadIdx.x >> 6));
     const int task = (blockIdx.x * WPB + (threadIdx.x >> 6)) * (64 / GL) + lane / GL;
     const bool valid = task < ntask;
     const DevTask T = tasks[valid ? task : ntask - 1];
@@ -479,6 +517,11 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
         }
     }
 
+    // ksw_nw / ksw_global: static band, no per-row cell masks (see wave_task); a task whose rows are over only keeps its H
+    constexpr bool STATIC_BAND = MODE != MODE_EXTEND;
+    bool dead[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) dead[c] = gl * C + c == 2 * w + 1;
     int beg = 0, end = qlen;
     int mx = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
     bool done = false;
@@ -515,7 +558,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int d = gl * C + c;
-            act[c] = live && d >= db && d < de;
+            act[c] = STATIC_BAND || (live && d >= db && d < de);
             const int hh = Hd[c] + score_at(mr, qc[c]);
             const int e = E[c];
             if (MODE == MODE_EXTEND) { A[c] = hh > e ? hh : e; dirH[c] = 0; }
@@ -550,10 +593,11 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
                 dd |= (f2 > t) ? 32u : 0u;
                 zpack |= (uint64_t)(act[c] ? dd : 0u) << (8 * c);
             }
-            Eo[c] = act[c] ? (e2 > t ? e2 : t) : (live ? FLOOR : E[c]);
+            if (STATIC_BAND) Eo[c] = dead[c] ? FLOOR : (e2 > t ? e2 : t);
+            else Eo[c] = act[c] ? (e2 > t ? e2 : t) : (live ? FLOOR : E[c]);
             const int tt = act[c] ? t : FLOOR;
             f = f2 > tt ? f2 : tt;
-            if (act[c]) Hd[c] = h;
+            if (STATIC_BAND ? live : act[c]) Hd[c] = h;
             if (MODE == MODE_EXTEND && act[c]) {
                 if (h >= m_l) { m_l = h; mj_l = base + gl * C + c; }
             }
@@ -642,7 +686,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
         {
             const int e_up = grp_shift_down1<GL>(Eo[0], FLOOR, gl);
             const uint32_t q_up = (uint32_t)grp_shift_down1<GL>((int)qc[0], (int)qfeed, gl);
-            if (live) {
+            if (STATIC_BAND || live) {
 #pragma unroll
                 for (int c = 0; c < C - 1; ++c) { E[c] = Eo[c + 1]; qc[c] = qc[c + 1]; }
                 E[C - 1] = e_up;
@@ -1420,6 +1464,7 @@ int pack_params(const alfa_dp_params* p, DevParams* dp) {
     for (int t = 0; t < p->m; ++t)
         for (int q = 0; q < p->m; ++q) dp->matrow[t] |= (uint64_t)(uint8_t)p->mat[t * p->m + q] << (8 * q);
     dp->m = p->m; dp->gapo = p->gapo; dp->gape = p->gape; dp->zdrop = p->zdrop;
+    for (int i = 0; i < p->m * p->m; ++i) dp->maxs = std::max<int>(dp->maxs, p->mat[i]);
     return ALFA_OK;
 }
 

@@ -31,6 +31,11 @@ import time
 
 import numpy as np
 
+# libalfa_hot sets GPU_MAX_HW_QUEUES to ALFA_HW_QUEUES (default 16) when it is loaded (csrc/device_ctx.hip); torch may initialise
+# HIP before that, so the same is done here
+if os.environ.get("ALFA_HW_QUEUES", "16") != "0":
+    os.environ["GPU_MAX_HW_QUEUES"] = str(min(32, max(1, int(os.environ.get("ALFA_HW_QUEUES", "16")))))
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

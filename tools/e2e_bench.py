@@ -78,11 +78,11 @@ def main():
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     md5s = {}
     for name in args.exe.split(","):
-        exe = EXES[name]
+        exe = EXES.get(name, os.path.join(ROOT, name))   # anything else: a path below the repository (an older build, for A/B runs)
         if not os.path.exists(exe):
             print(name, "missing")
             continue
-        out = os.path.join(args.dir, "out_%s.sam" % name)
+        out = os.path.join(args.dir, "out_%s.sam" % name.replace("/", "_"))
         inputs = ["-1", mates[0], "-2", mates[1], "-I", "250", "-X", "650"] if args.paired else ["-0", fq]
         cmd = [exe, "align", "-i", idx] + inputs + ["-o", out, "-t", str(args.threads)] + args.extra.split()
         if name != "ref":

@@ -3,6 +3,7 @@
 
 usage: rocprof_summary.py kernels <dir-or-db> <out.csv>          per-kernel calls / total / average / min / max / %
        rocprof_summary.py timeline <dir-or-db> <out.csv>         how the kernels overlap: busy fraction, time alone / shared
+       rocprof_summary.py dispatches <dir-or-db> <out.csv>       every dispatch in start order (start, duration, queue/stream ids)
        rocprof_summary.py pmc     <dir-or-db> <out.csv> [--json out.json --batch N --note "..."]
                                                                  per-kernel mean of every collected counter per dispatch;
                                                                  the JSON form keeps FETCH_SIZE / WRITE_SIZE as bytes per dispatch
@@ -147,6 +148,25 @@ def timeline(path, out, only=""):
     print(open(out).read())
 
 
+def dispatches(path, out, only=""):
+    """every kernel dispatch in start order: start (us since the first), duration (us), queue / stream ids when the
+    database has them, name -- to read how the launches of one step overlap"""
+    rows = []
+    for d in select_dbs(path, only):
+        con = sqlite3.connect(d)
+        cols = [r[1] for r in con.execute("pragma table_info('kernels')")]
+        extra = [c for c in cols if ("queue" in c or "stream" in c) and c.endswith("id")]
+        for r in con.execute("select name, start, end%s from kernels" % "".join(", " + c for c in extra)):
+            rows.append((r[1], r[2], short(r[0])) + tuple(r[3:]))
+    rows.sort()
+    t0 = rows[0][0] if rows else 0
+    with open(out, "w") as f:
+        f.write("start_us,dur_us,%skernel\n" % "".join(c + "," for c in (extra if rows else [])))
+        for r in rows:
+            f.write("%.1f,%.1f,%s\"%s\"\n" % ((r[0] - t0) / 1e3, (r[1] - r[0]) / 1e3, "".join(str(x) + "," for x in r[3:]), r[2]))
+    print("%d dispatches -> %s" % (len(rows), out))
+
+
 def pmc(path, out, jout=None, batch=None, note="", only=""):
     agg = defaultdict(lambda: defaultdict(list))
     for d in select_dbs(path, only):
@@ -178,7 +198,7 @@ def pmc(path, out, jout=None, batch=None, note="", only=""):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["kernels", "pmc", "timeline"])
+    ap.add_argument("mode", choices=["kernels", "pmc", "timeline", "dispatches"])
     ap.add_argument("src")
     ap.add_argument("out")
     ap.add_argument("--json")
@@ -190,6 +210,8 @@ def main():
         sys.exit("no rocprofv3 .db under " + a.src)
     if a.mode == "timeline":
         timeline(a.src, a.out, a.only)
+    elif a.mode == "dispatches":
+        dispatches(a.src, a.out, a.only)
     elif a.mode == "kernels":
         for k, v in kernels(a.src, a.out, a.only)[:12]:
             print("%-60s calls %5d avg %10.1f us" % (k[:60], len(v), sum(v) / len(v) / 1e3))
