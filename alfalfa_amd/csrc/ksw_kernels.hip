@@ -105,13 +105,14 @@ __device__ __forceinline__ int score_of(uint64_t mr, uint32_t q) { return (int)(
 // the same with the residue kept as its shift amount (8 x code): the band kernels carry query residues in that form
 __device__ __forceinline__ int score_at(uint64_t mr, uint32_t q8) { return (int)(int8_t)(mr >> q8); }
 
-// A launch is ordered longest task first and ends when its longest task does: a wavefront's rows are a serial chain of a few
-// hundred instructions each, so a 10 000-row task takes milliseconds even with a SIMD to itself, and several times that
-// when it shares the SIMD's issue slots evenly with three shorter neighbours.  The first wavefronts of a launch therefore
-// raise their issue priority (s_setprio): the long chains run at nearly their solo speed and the rest fills the gaps.
-__device__ __forceinline__ void rank_priority(int wave_rank) {
-    if (wave_rank < 1024) __builtin_amdgcn_s_setprio(3);
-    else if (wave_rank < 3072) __builtin_amdgcn_s_setprio(1);
+// A wavefront's rows are a serial chain of 100-200 instructions each at ~6 cycles per instruction: a 10 000-row task takes
+// milliseconds even with a SIMD to itself (tools/dp_long_probe.py: 232 / 360 / 491 ns per row for ksw_nw / ksw_global /
+// ksw_extend at 201 diagonals), and a call ends when its longest chain does.  Wavefronts with long chains therefore raise
+// their issue priority (s_setprio) over the crowd of short tasks that shares their SIMD.
+__device__ __forceinline__ void chain_priority(int rows) {
+    if (rows >= 4096) __builtin_amdgcn_s_setprio(3);
+    else if (rows >= 2048) __builtin_amdgcn_s_setprio(2);
+    else if (rows >= 1024) __builtin_amdgcn_s_setprio(1);
 }
 
 // ---------------------------------------------------------------- wave-per-task kernel
@@ -393,8 +394,8 @@ __global__ __launch_bounds__(64 * WPB) void ksw_wave_kernel(const DevTask* __res
                                                            int32_t* __restrict__ out, uint8_t* __restrict__ zbuf) {
     const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (wave >= ntask) return;
-    rank_priority(wave);
     const DevTask T = tasks[wave];
+    chain_priority(__builtin_amdgcn_readfirstlane(T.tlen));
     if (MODE == MODE_EXTEND && wave_task_packs(T, prm)) wave_task<MODE, C, true>(T, seq, prm, out, zbuf);
     else wave_task<MODE, C>(T, seq, prm, out, zbuf);
 }
@@ -480,7 +481,6 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
     __syncthreads();
     const int lane = lane_id();
     const int gl = lane & (GL - 1);
-    rank_priority(blockIdx.x * WPB + (threadIdx.x >> 6));
     const int task = (blockIdx.x * WPB + (threadIdx.x >> 6)) * (64 / GL) + lane / GL;
     const bool valid = task < ntask;
     const DevTask T = tasks[valid ? task : ntask - 1];
@@ -530,6 +530,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
     if (GL == 8) tmax = max(tmax, __shfl_xor(tmax, 8, 64));
     tmax = max(tmax, __shfl_xor(tmax, 16, 64));
     tmax = max(tmax, __shfl_xor(tmax, 32, 64));
+    chain_priority(__builtin_amdgcn_readfirstlane(tmax));
     uint32_t tnext = tlen > 0 ? tg[0] : 0u;           // target residue of row i, fetched one row ahead
     uint64_t mr = s_mat[tnext & 7];
     tnext = tlen > 1 ? tg[1] : 0u;
@@ -766,6 +767,7 @@ __global__ __launch_bounds__(64) void ksw_backtrack_tile_kernel(const DevTask* _
     const DevTask T = tasks[t];
     const int qlen = T.qlen, tlen = T.tlen, w = T.w;
     if (tlen > qlen + w) { if (lane == 0) ncig[T.orig] = -1; return; }   // reference indexes outside the matrix: unspecified
+    chain_priority(__builtin_amdgcn_readfirstlane(tlen));
     uint32_t* slot = cig + T.cigoff;
     int pos = T.cigcap, n = 0;
     uint32_t cur_op = 0xffffffffu, cur_len = 0;
