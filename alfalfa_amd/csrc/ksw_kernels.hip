@@ -224,13 +224,17 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
             const int bv = MODE == MODE_EXTEND ? sub_floor0(A[c], gapoe) : A[c] - gapoe;      // ksw_extend clamps at 0 (A >= 0 there)
             Bv[c] = act[c] ? bv : FLOOR;
         }
-        // lane-local contribution to the F chain, then the cross-lane max-plus scan
-        int L = Bv[0];
+        // lane-local contribution to the F chain, then the cross-lane max-plus scan.  P[c] = what the lane's cells before c
+        // hand to cell c: F(c) = max(f_in - c*gape, P[c]) for every cell at once instead of a chain through the cells
+        // (F(c+1) = max(F(c) - gape, max(A(c), F(c)) - gapoe) = max(F(c) - gape, Bv(c)) because gapoe >= gape)
+        int P[C + 1];
+        P[1] = Bv[0];
 #pragma unroll
-        for (int c = 1; c < C; ++c) L = max(L - gape, Bv[c]);
+        for (int c = 1; c < C; ++c) P[c + 1] = max(P[c] - gape, Bv[c]);
+        const int L = P[C];
         const int Cg = C * gape;
         const int gx = wave_excl_max_scan(L + lane * Cg, 0);
-        int f = lane == 0 ? FLOOR : gx - (lane - 1) * Cg;
+        const int f_in = lane == 0 ? FLOOR : gx - (lane - 1) * Cg;
 
         int Hrow[C], Eo[C];
         uint32_t zpack = 0;
@@ -239,7 +243,7 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
         int zl_l = -1, zr_l = 0x7fffffff;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const int F = f;
+            const int F = c == 0 ? f_in : max(f_in - c * gape, P[c]);
             int h = A[c];
             uint32_t dd = dirH[c];
             if (MODE == MODE_EXTEND) { h = h > F ? h : F; }
@@ -254,8 +258,6 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
                 zpack |= (act[c] ? dd : 0u) << (8 * c);
             }
             Eo[c] = (STATIC_BAND ? !dead[c] : act[c]) ? (e2 > t ? e2 : t) : FLOOR;
-            const int tt = act[c] ? t : FLOOR;
-            f = f2 > tt ? f2 : tt;
             if (act[c]) Hd[c] = h;
             if (MODE == MODE_EXTEND) {
                 const int hx = act[c] ? h : -1;
@@ -301,20 +303,25 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
             }
             const int mrow = m < 0 ? 0 : m;
             const int mjrow = m < 0 ? -1 : mj;
+            // (straight-line scalar code: every instruction of the row is on the task's critical path, branches most of all)
             {
                 int dlt = (i - max_i) - (jfin - max_j);
                 dlt = dlt < 0 ? -dlt : dlt;
-                if (mrow == 0 || (zdrop > 0 && mx - mrow - dlt * gape > zdrop)) break;   // ksw.c:429
+                const int stop = (int)(mrow == 0) | ((int)(zdrop > 0) & (int)(mx - mrow - dlt * gape > zdrop));   // ksw.c:429
+                if (stop) break;
             }
-            if (mrow > mx) {
-                mx = mrow; max_i = i; max_j = mjrow;
+            {
+                const bool up = mrow > mx;
                 int off = mjrow - i; off = off < 0 ? -off : off;
-                max_off = max_off > off ? max_off : off;
+                off = max_off > off ? max_off : off;
+                mx = up ? mrow : mx; max_i = up ? i : max_i; max_j = up ? mjrow : max_j; max_off = up ? off : max_off;
             }
             // ---- band shrink (ksw.c:435-438) in terms of this row's H values:
             //   eh[j].h == H(i,j-1) for beg<j<=end, eh[beg].h == h1_init
-            // (an in-band zero is rare while the extension is alive: the two reductions run only when a lane holds one)
-            int zl = -1, zr = 0x7fffffff;
+            // without an in-band zero the band keeps its left edge (or loses one column once the first-column value is 0) and
+            // grows by one column on the right; a zero is rare while the extension is alive, and only then are the two
+            // reductions run
+            int nbeg = beg + (int)(h1_init == 0), nend = end + 1;
             if (__ballot(hmin_l == 0)) {        // wave-uniform
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
@@ -324,8 +331,10 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
                         if (j >= mjrow + 1 && j < zr_l) zr_l = j;
                     }
                 }
-                zl = wave_max(zl_l);
-                zr = wave_min(zr_l);
+                const int zl = wave_max(zl_l);
+                const int zr = wave_min(zr_l);
+                if (zl >= 0) nbeg = zl + 2;
+                if (zr != 0x7fffffff) nend = zr + 1;
             }
             // inject H(i, beg-1) := h1_init on the diagonal just left of the band (read by row i+1 if beg stays)
             {
@@ -336,12 +345,8 @@ __device__ __forceinline__ void wave_task(const DevTask T, const uint8_t* __rest
                         if (lane * C + c == di) Hd[c] = h1_init;
                 }
             }
-            int nbeg;
-            if (zl >= 0) nbeg = zl + 2;
-            else if (h1_init == 0) nbeg = beg + 1;
-            else nbeg = beg;
             beg = nbeg;
-            end = (zr != 0x7fffffff) ? zr + 1 : end + 1;
+            end = nend;
         } else {
             // first-column value H(i,-1) for the next row while the band still touches column 0 (ksw.c:497,568)
             const int di = w - i - 1;
@@ -567,12 +572,14 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
             const int bv = MODE == MODE_EXTEND ? sub_floor0(A[c], gapoe) : A[c] - gapoe;      // ksw_extend clamps at 0 (A >= 0 there)
             Bv[c] = act[c] ? bv : FLOOR;
         }
-        int L = Bv[0];
+        int P[C + 1];                  // see wave_task: F(c) = max(f_in - c*gape, P[c])
+        P[1] = Bv[0];
 #pragma unroll
-        for (int c = 1; c < C; ++c) L = max(L - gape, Bv[c]);
+        for (int c = 1; c < C; ++c) P[c + 1] = max(P[c] - gape, Bv[c]);
+        const int L = P[C];
         const int Cg = C * gape;
         const int gx = (MODE == MODE_EXTEND && GL == 16) ? row_excl_max_scan_nonneg(L + gl * Cg) : grp_excl_max_scan<GL>(L + gl * Cg, 0, gl);
-        int f = gl == 0 ? FLOOR : gx - (gl - 1) * Cg;
+        const int f_in = gl == 0 ? FLOOR : gx - (gl - 1) * Cg;
 
         int Hrow[C], Eo[C];
         uint64_t zpack = 0;
@@ -580,7 +587,7 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
         int zl_l = -1, zr_l = 0x7fffffff;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const int F = f;
+            const int F = c == 0 ? f_in : max(f_in - c * gape, P[c]);
             int h = A[c];
             uint32_t dd = dirH[c];
             if (MODE == MODE_EXTEND) { h = h > F ? h : F; }
@@ -596,8 +603,6 @@ __global__ __launch_bounds__(64 * WPB) void ksw_group_kernel(const DevTask* __re
             }
             if (STATIC_BAND) Eo[c] = dead[c] ? FLOOR : (e2 > t ? e2 : t);
             else Eo[c] = act[c] ? (e2 > t ? e2 : t) : (live ? FLOOR : E[c]);
-            const int tt = act[c] ? t : FLOOR;
-            f = f2 > tt ? f2 : tt;
             if (STATIC_BAND ? live : act[c]) Hd[c] = h;
             if (MODE == MODE_EXTEND && act[c]) {
                 if (h >= m_l) { m_l = h; mj_l = base + gl * C + c; }
