@@ -14,7 +14,10 @@
 // (tools/gpu_queue_ab.sh): 12.5 ms per step with 4 queues, 10.7 with 8, 7.9 with 16, 8.1-8.2 with 24-32; the C3 step is
 // unchanged (0.58-0.59 ms).  The library therefore sets GPU_MAX_HW_QUEUES to ALFA_HW_QUEUES (default 16, at most 32) when it
 // is loaded; ALFA_HW_QUEUES=0 leaves the variable alone.  The HIP runtime reads it when it initialises (its first call), so
-// a host that has used HIP before loading the library keeps whatever it had.
+// a host that has used HIP before loading the library keeps whatever it had.  Queues of all processes on a GPU share its
+// hardware slots: beyond them the driver time-slices (a 4-queue tool beside a 16-queue process is fine, two 16-queue
+// processes are not: 1.6 -> 2.4 s per million reads end to end), so hosts that run several processes per GPU set ALFA_HW_QUEUES
+// lower; the command line tool does (mapper/alfalfa_main.cpp).
 __attribute__((constructor)) static void alfa_default_hw_queues() {
     const char* e = getenv("ALFA_HW_QUEUES");
     int n = e ? atoi(e) : 16;

@@ -14,6 +14,13 @@ static int physical(int device) {
 }
 
 int main(int argc, char** argv) {
+    // libalfa_hot raises GPU_MAX_HW_QUEUES to 16 when it is loaded (device_ctx.hip), which pays when one caller overlaps large
+    // batches of every ksw kind.  The mapper's threads issue small synchronous batches: end to end it is the same with 4 or
+    // 16 queues (tools/gpu_queue_ab2.sh), and several mapper processes may share a GPU -- once the queues of all processes
+    // on a GPU exceed its hardware slots the driver time-slices them (this tool beside a 16-queue process: 1.6 -> 2.4 s per
+    // million reads).  So the tool goes back to HIP's default of 4 unless ALFA_HW_QUEUES says otherwise; nothing has
+    // initialised HIP yet at this point.
+    if (!getenv("ALFA_HW_QUEUES")) (void)setenv("GPU_MAX_HW_QUEUES", "4", 1);
     alfa::HotBinding b;
     b.make_ops = [](int device, const alfa_host_index* hidx, alfa::HotOps* ops) {
         device = physical(device);
