@@ -1625,8 +1625,14 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
     static const int side_mod = [] { const char* e = getenv("ALFA_SIDE_STREAMS"); int v = e ? atoi(e) : alfa::Ctx::NSIDE; return v < 1 ? 1 : (v > alfa::Ctx::NSIDE ? alfa::Ctx::NSIDE : v); }();
     auto side = [&](int k) -> hipStream_t {
         k %= side_mod;
-        if (!forked) { (void)hipEventRecord(cx->fork_ev, st); forked = true; }
-        if (!used[k]) { (void)hipStreamWaitEvent(cx->side[k], cx->fork_ev, 0); used[k] = true; }
+        // a synchronous call orders its side chains behind the caller's stream; with lazy joins the chains are only ordered
+        // among themselves (each side stream is in order) and joined at the next fetch / sync: a batch's inputs were uploaded
+        // and waited for when it was created, so nothing on `st` -- e.g. the seed kernels of other reads -- has to finish first
+        if (!cx->lazy_join) {
+            if (!forked) { (void)hipEventRecord(cx->fork_ev, st); forked = true; }
+            if (!used[k]) (void)hipStreamWaitEvent(cx->side[k], cx->fork_ev, 0);
+        }
+        used[k] = true;
         return cx->side[k];
     };
     for (int g = 0; g < 3; ++g) {
