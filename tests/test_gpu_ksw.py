@@ -88,3 +88,32 @@ def test_extend_dead_boundary_cells(gpu):
     e, eo = ffi.ksw_extend_batch(P, tasks), O.orc_ksw_extend_batch(P, tasks)
     bad = np.nonzero(e != eo)[0]
     assert len(bad) == 0, [(int(i), ws[i], hs[i], e[i], eo[i]) for i in bad[:5]]
+
+
+def test_lazy_join_overlapped_batches(gpu):
+    """alfa_set_lazy_join: six resident batches (two per ksw kind, short and long tasks) launched back to back, twice, with
+    no synchronisation in between -- their kernel bins run on side streams that are only joined at the first fetch -- and every
+    result equals the oracle's."""
+    P = ffi.default_params()
+    sets = []
+    for seed, (rl, err, band) in enumerate([(250, 0.02, 21), (3000, 0.1, 100)]):
+        pairs, ws, hs = dpgen.mapper_like_tasks(40 + seed, 300, rl, err, band)
+        tasks, keep = ffi.make_dp_tasks(pairs, ws, hs)
+        sets.append((pairs, ws, tasks, keep))
+    ffi.set_lazy_join(0, True)
+    try:
+        batches = [(mode, k, ffi.DpBatch(mode, P, sets[k][2], 0)) for k in range(2) for mode in (ffi.DP_EXTEND, ffi.DP_NW, ffi.DP_GLOBAL)]
+        for _ in range(2):
+            for _, _, b in batches:
+                b.launch()
+        got = [(mode, k, b.fetch()) for mode, k, b in batches]
+    finally:
+        ffi.set_lazy_join(0, False)
+    for mode, k, res in got:
+        pairs, ws, tasks, _ = sets[k]
+        if mode == ffi.DP_EXTEND:
+            assert np.array_equal(res, O.orc_ksw_extend_batch(P, tasks))
+        elif mode == ffi.DP_NW:
+            assert np.array_equal(res, O.orc_ksw_nw_batch(P, tasks))
+        else:
+            _cmp_global(res, O.orc_ksw_global_batch(P, tasks), pairs, ws)
