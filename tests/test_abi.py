@@ -52,3 +52,20 @@ def test_product_does_not_reference_oracle():
         if os.path.isfile(f) and f.endswith((".py", ".cpp", ".hip", ".h")):
             txt = open(f, errors="ignore").read()
             assert "oracle/" not in txt and "liboracle" not in txt and "alfa_oracle" not in txt, f
+
+
+@pytest.mark.parametrize("knob,before,expect", [(None, None, "16"), (None, "4", "16"), ("8", None, "8"), ("0", "5", "5"), ("0", None, None)])
+def test_hw_queue_default_is_set_at_load(knob, before, expect):
+    """loading the library sets the HIP runtime's hardware-queue count to ALFA_HW_QUEUES (default 16; 0 = hands off): see
+    csrc/device_ctx.hip.  Checked in a child process through libc's getenv (the variable is set from C)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("ALFA_HW_QUEUES", "GPU_MAX_HW_QUEUES")}
+    if knob is not None:
+        env["ALFA_HW_QUEUES"] = knob
+    if before is not None:
+        env["GPU_MAX_HW_QUEUES"] = before
+    code = ("import ctypes, sys; ctypes.CDLL(sys.argv[1]); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "v = libc.getenv(b'GPU_MAX_HW_QUEUES'); print('unset' if v is None else v.decode())")
+    out = subprocess.run([sys.executable, "-c", code, ffi.LIB_PATH], env=env, stdout=subprocess.PIPE, check=True).stdout.decode().strip()
+    assert out == ("unset" if expect is None else expect)
