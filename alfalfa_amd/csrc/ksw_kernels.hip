@@ -1476,11 +1476,9 @@ int pack_params(const alfa_dp_params* p, DevParams* dp) {
 }
 
 // effective band: ksw_extend's max_gap clamp (ksw.c:381-386) then the exact no-op clamp to max(qlen,tlen)
-int effective_w(int mode, const alfa_dp_params* p, const alfa_dp_task& x) {
+int effective_w(int mode, const alfa_dp_params* p, const alfa_dp_task& x, int maxs) {      // maxs: largest matrix entry (>= 0)
     int w = x.w;
     if (mode == MODE_EXTEND) {
-        int maxs = 0;
-        for (int i = 0; i < p->m * p->m; ++i) maxs = maxs > p->mat[i] ? maxs : p->mat[i];
         int max_gap = p->gape > 0 ? (int)((double)(x.qlen * maxs - p->gapo) / p->gape + 1.) : 0x3fffffff;
         max_gap = max_gap > 1 ? max_gap : 1;
         w = w < max_gap ? w : max_gap;
@@ -1490,15 +1488,16 @@ int effective_w(int mode, const alfa_dp_params* p, const alfa_dp_task& x) {
     return w;
 }
 
-// cells of the static band envelope: sum_i (min(i+w+1,qlen) - max(i-w,0))^+   
+// cells of the static band envelope: sum_i (min(i+w+1,qlen) - max(i-w,0))^+   (SURVEY 8d), in closed form (a loop over the
+// rows of every task was a tenth of the host time of a call)
 int64_t band_cells(int64_t qlen, int64_t tlen, int64_t w) {
-    int64_t c = 0;
-    // closed form would do; rows are few enough to take the three regimes directly
-    for (int64_t i = 0; i < tlen; ++i) {
-        const int64_t b0 = i > w ? i - w : 0, e0 = std::min<int64_t>(i + w + 1, qlen);
-        if (e0 > b0) c += e0 - b0; else if (b0 >= qlen) break;
-    }
-    return c;
+    if (qlen <= 0 || tlen <= 0) return 0;
+    const int64_t T = std::min(tlen, qlen + w);                      // rows whose band still meets the query
+    const int64_t a = std::min(std::max<int64_t>(qlen - w, 0), T);   // rows whose right edge is i + w + 1
+    const int64_t b = std::min(w + 1, T);                            // rows whose left edge is column 0
+    const int64_t hi = a * (w + 1) + a * (a - 1) / 2 + (T - a) * qlen;
+    const int64_t lo = (T * (T - 1) / 2 - b * (b - 1) / 2) - (T - b) * w;
+    return hi - lo;
 }
 
 // ksw_lane2_kernel's classes: ND band diagonals over G lanes.  A band width has a narrow form (few lanes per task: least
@@ -1518,7 +1517,7 @@ size_t lane2_lds(int mode, int nd, int g, int tcap) {
     const size_t tw = (size_t)(tcap + g + 11) >> 2;
     return 64 + (rw + tw) * tpw * 4 + (mode == MODE_GLOBAL ? (size_t)(tcap + 1) * (nd / 4) * tpw * 2 : 0);
 }
-int lane2_class(int mode, const alfa_dp_params* p, const alfa_dp_task& x, int w, int rows) {
+int lane2_class(int mode, const alfa_dp_params* p, const alfa_dp_task& x, int w, int rows, int maxs) {
     static const bool off = getenv("ALFA_DP_NO_LANE2") != nullptr;
     static const int64_t latcap_env = getenv("ALFA_DP_LATCAP") ? atoll(getenv("ALFA_DP_LATCAP")) : 0;
     static const int64_t latcap_mode[3] = {16000, 16000, 24000};       // measured on the C3 stream (tools/dp_replay.py sweeps)
@@ -1532,8 +1531,6 @@ int lane2_class(int mode, const alfa_dp_params* p, const alfa_dp_task& x, int w,
     if (W > 64) return -1;
     if (mode == MODE_EXTEND) {
         // scores stay far below 2^25 (packed row-maximum key)
-        int maxs = 0;
-        for (int i = 0; i < p->m * p->m; ++i) maxs = std::max<int>(maxs, p->mat[i]);
         const int h0 = x.h0 < 0 ? 0 : x.h0;
         if ((int64_t)h0 + (int64_t)x.qlen * maxs >= (1 << 24)) return -1;
         // the first-column value h0 - gapo - gape*(i+1) must stay positive for as long as the band touches column 0 (rows
@@ -1733,7 +1730,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         const alfa_dp_task& x = t[ids ? ids[i] : i];
         if (x.qlen < 0 || x.tlen < 0 || x.w < 0) return alfa::fail(ALFA_EINVAL, "negative length or band in a DP task");
         if ((x.qlen > 0 && !x.query) || (x.tlen > 0 && !x.target)) return alfa::fail(ALFA_EINVAL, "null sequence pointer in a DP task");
-        w_eff[i] = effective_w(mode, p, x);
+        w_eff[i] = effective_w(mode, p, x, b->hp.maxs);
         // ksw_extend never gets past row qlen + w: there beg = i - w reaches qlen and the reference leaves its row loop
         // (ksw.c:393-423), so the rows behind it are dropped here, for every kernel
         rows_eff[i] = mode == MODE_EXTEND ? (int)std::min<int64_t>(x.tlen, (int64_t)x.qlen + w_eff[i] + 1) : x.tlen;
@@ -1744,7 +1741,7 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         else {
             const int W = 2 * w_eff[i] + 1;
             bin = W <= 16 ? 3 : W <= 32 ? 4 : W <= 64 ? 5 : W <= 128 ? 6 : W <= 256 ? 7 : 8;
-            const int l2 = lane2_class(mode, p, x, w_eff[i], rows_eff[i]);
+            const int l2 = lane2_class(mode, p, x, w_eff[i], rows_eff[i], b->hp.maxs);
             if (l2 >= 0) bin = L2BIN + l2;
         }
         bins[i] = bin;
@@ -1761,11 +1758,22 @@ int fill_batch(alfa_dp_batch* b, Ctx* cx, int mode, const alfa_dp_params* p, con
         const alfa_dp_task& x = t[ids ? ids[i] : i];
         work[i] = bins[i] < 3 ? (int64_t)rows_eff[i] * std::min<int64_t>(x.qlen, 2 * (int64_t)w_eff[i] + 1) : (int64_t)rows_eff[i];
     }
-    std::sort(perm.begin(), perm.end(), [&](int a, int c) {
-        if (bins[a] != bins[c]) return bins[a] < bins[c];
-        if (work[a] != work[c]) return work[a] > work[c];
-        return a < c;
-    });
+    if (n < (1 << 26)) {
+        // one 64-bit key per task (bin, work descending, index): sorting plain integers is several times faster than a
+        // comparator that chases three arrays, and this sort was a third of the host time of a call
+        std::vector<uint64_t> key((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            const uint64_t wk = 0xffffffffull - (uint64_t)std::min<int64_t>(work[i], 0xffffffffll);
+            key[i] = (uint64_t)bins[i] << 58 | wk << 26 | (uint64_t)i;
+        }
+        std::sort(key.begin(), key.end());
+        for (int i = 0; i < n; ++i) perm[i] = (int)(key[i] & ((1u << 26) - 1));
+    } else
+        std::sort(perm.begin(), perm.end(), [&](int a, int c) {
+            if (bins[a] != bins[c]) return bins[a] < bins[c];
+            if (work[a] != work[c]) return work[a] > work[c];
+            return a < c;
+        });
     b->seq_bytes = seq_bytes;
     if ((rc = cx->h_in.reserve(seq_bytes + 96)) || (rc = cx->h_tasks.reserve(sizeof(DevTask) * (size_t)n + sizeof(DevParams))) ||
         (rc = b->d_seq.reserve(seq_bytes + 96)) || (rc = b->d_tasks.reserve(sizeof(DevTask) * (size_t)n + sizeof(DevParams))))
