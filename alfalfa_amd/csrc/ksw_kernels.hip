@@ -26,6 +26,7 @@
 //   * Tasks whose band does not fit 256 diagonals, and degenerate 0-length tasks, run in a
 //     lane-per-task kernel that follows the reference loop literally (the rare tail).
 //   * The kernel bins of a batch run as independent chains on side streams (launch_all).
+#include <chrono>
 #include <algorithm>
 #include <memory>
 #include <atomic>
@@ -2017,9 +2018,18 @@ int run_sync(int mode, const alfa_dp_params* p, const alfa_dp_task* t, int n, vo
         auto flush = [&]() -> int {
             if (ids.empty()) return ALFA_OK;
             int r;
+            static const bool call_log = getenv("ALFA_CALL_LOG") != nullptr;      // diagnostics: where a synchronous call's time goes
+            const auto t0 = std::chrono::steady_clock::now();
             if ((r = fill_batch(b, cx, mode, p, t, ids.data(), (int)ids.size()))) return r;
+            const auto t1 = std::chrono::steady_clock::now();
             if ((r = launch_batch(b, cx))) return r;
             if ((r = fetch_batch(b, cx, out, ids.data(), mode == MODE_GLOBAL ? &cigs : nullptr, ncig))) return r;
+            if (call_log) {
+                const auto t2 = std::chrono::steady_clock::now();
+                fprintf(stderr, "#CALL mode %d tasks %d seq_bytes %zu z_bytes %lld fill_ms %.3f run_fetch_ms %.3f kernel_ms %.3f\n", mode, (int)ids.size(),
+                        b->seq_bytes, (long long)b->zbytes, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                        std::chrono::duration<double, std::milli>(t2 - t1).count(), b->kernel_ms);
+            }
             alfa::g_last_timing.kernel_ms += b->kernel_ms;
             alfa::g_last_timing.work_units += b->cells;
             alfa::g_last_timing.launches += 1;
