@@ -1,6 +1,7 @@
 // device_ctx.hip -- see device_ctx.h
 #include "device_ctx.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -33,7 +34,9 @@ namespace alfa {
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap) return ALFA_OK;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-    size_t want = bytes + bytes / 4 + 256;
+    // growing is expensive beyond the allocation itself: hipFree waits for the whole device, i.e. for the kernels of every
+    // other host thread (milliseconds each on long reads), so a buffer doubles (up to 256 MiB of headroom) rather than creep
+    size_t want = bytes + std::min<size_t>(bytes, (size_t)256 << 20) + 256;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
         p = nullptr;
@@ -49,7 +52,7 @@ void DevBuf::release() {
 int PinBuf::reserve(size_t bytes) {
     if (bytes <= cap) return ALFA_OK;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-    size_t want = bytes + bytes / 4 + 256;
+    size_t want = bytes + std::min<size_t>(bytes, (size_t)64 << 20) + 256;
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
     if (e != hipSuccess) {
         p = nullptr;
