@@ -1112,7 +1112,6 @@ __device__ __forceinline__ void lane2_body(const DevTask* __restrict__ tasks, in
     // (ksw_extend tasks whose first-column value max(h0 - gapo - gape*(i+1), 0) reaches 0 while the band still touches column 0
     // never come here -- lane2_class: the reference may then move `beg` depending on E at the band's edge, ksw.c:435-436)
     const int tmax = wave_max(tlen);
-    const int qmax = wave_max(valid ? qlen : 0);
 
     // ---- the task's query string: PAD everywhere, query residue j at byte j + w (dword d of task tw at ring[d * TPW + tw]);
     // its target string: residue r at byte r + G (lane g reads byte k + G - g in iteration k), 0 elsewhere
