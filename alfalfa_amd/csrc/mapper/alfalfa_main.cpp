@@ -19,8 +19,8 @@ int main(int argc, char** argv) {
     // batches of every ksw kind.  The mapper's threads issue small synchronous batches: end to end it is the same with 4 or
     // 16 queues (tools/gpu_queue_ab2.sh), and several mapper processes may share a GPU -- once the queues of all processes
     // on a GPU exceed its hardware slots the driver time-slices them (this tool beside a 16-queue process: 1.6 -> 2.4 s per
-    // million reads).  So the tool goes back to HIP's default of 4 unless ALFA_HW_QUEUES says otherwise; nothing has
-    // initialised HIP yet at this point.
+    // million reads).  So the tool goes back to HIP's default of 4 unless ALFA_HW_QUEUES says otherwise (8 is worth ~5 % on long
+    // reads: 1.93-2.05 -> 1.86-1.94 s per 50 000 reads, nothing on 250-bp reads); nothing has initialised HIP yet at this point.
     if (!getenv("ALFA_HW_QUEUES")) (void)setenv("GPU_MAX_HW_QUEUES", "4", 1);
     // 16 workers build and drop reads, task copies and CIGAR vectors of 10-100 KiB all the time: keep such blocks in the heap
     // (glibc would mmap/munmap each one above 128 KiB and trim the heap top after frees; every fresh page then faults under the
