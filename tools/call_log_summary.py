@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""tools/call_log_summary.py <stderr log> -- sums the `#CALL` lines a run with ALFA_CALL_LOG=1 prints (one per synchronous
+DP call: mode 0 nw / 1 global / 2 extend, tasks, sequence and direction bytes, packing ms, run+fetch ms, kernel ms) and
+repeats the tool's #STATS / #PHASES lines.  Development aid for the end-to-end tool."""
 import collections,sys
 agg=collections.defaultdict(lambda:[0,0,0,0,0,0,0])
 for l in open(sys.argv[1]):
