@@ -117,3 +117,17 @@ def test_lazy_join_overlapped_batches(gpu):
             assert np.array_equal(res, O.orc_ksw_nw_batch(P, tasks))
         else:
             _cmp_global(res, O.orc_ksw_global_batch(P, tasks), pairs, ws)
+
+
+@pytest.mark.parametrize("band", [40, 100])
+def test_extend_large_scores_two_reduction_form(gpu, band):
+    """ksw_extend tasks whose scores can pass 2^22 (here through h0) take the wave kernel's two-reduction form of the row
+    maximum instead of the packed (H << 8 | diagonal) key; bands of 81 / 201 diagonals = the 128- and 256-diagonal kernels."""
+    pairs, ws, hs = dpgen.mapper_like_tasks(90 + band, 200, 600, 0.08, band)
+    hs = [5_000_000 + 7 * i for i in range(len(pairs))]
+    P = ffi.default_params()
+    tasks, keep = ffi.make_dp_tasks(pairs, ws, hs)
+    e = ffi.ksw_extend_batch(P, tasks)
+    eo = O.orc_ksw_extend_batch(P, tasks)
+    bad = np.nonzero(e != eo)[0]
+    assert len(bad) == 0, [(int(i), len(pairs[i][0]), len(pairs[i][1]), ws[i], hs[i], e[i], eo[i]) for i in bad[:5]]
