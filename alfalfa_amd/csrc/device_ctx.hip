@@ -12,22 +12,32 @@
 // Hardware queues.  A DP call forks its kernel bins onto side streams (ksw_kernels.hip: launch_all) and a mapper thread adds
 // its seed and upload streams; HIP multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (4 unless the
 // variable says otherwise), and streams that share a queue run one after the other.  Measured on the C4 stream
-// (tools/gpu_queue_ab.sh): 12.5 ms per step with 4 queues, 10.7 with 8, 7.9 with 16, 8.1-8.2 with 24-32; the C3 step is
-// unchanged (0.58-0.59 ms).  The library therefore sets GPU_MAX_HW_QUEUES to ALFA_HW_QUEUES (default 16, at most 32) when it
-// is loaded; ALFA_HW_QUEUES=0 leaves the variable alone.  The HIP runtime reads it when it initialises (its first call), so
-// a host that has used HIP before loading the library keeps whatever it had.  Queues of all processes on a GPU share its
-// hardware slots: beyond them the driver time-slices (a 4-queue tool beside a 16-queue process is fine, two 16-queue
-// processes are not: 1.6 -> 2.4 s per million reads end to end), so hosts that run several processes per GPU set ALFA_HW_QUEUES
-// lower; the command line tool does (mapper/alfalfa_main.cpp).
+// (tools/gpu_queue_ab.sh, driven through ALFA_HW_QUEUES): 12.5 ms per step with 4 queues, 10.7 with 8, 7.9 with 16, 8.1-8.2
+// with 24-32; the C3 step is unchanged.
+// The HOST chooses the queue count: a GPU_MAX_HW_QUEUES that is already in the environment is never touched.  Only when the
+// variable is absent does loading the library install a default of 16; ALFA_HW_QUEUES=<n> is the operator's explicit request
+// to this library and wins (0 = hands off altogether).  The HIP runtime reads the variable when it initialises (its first
+// call), so a host that has used HIP before loading the library keeps whatever it had.  Queues of all processes on a GPU
+// share its hardware slots: beyond them the driver time-slices (two 16-queue processes on one GPU: 1.6 -> 2.4 s per million
+// reads end to end), so hosts that run several processes per GPU choose a lower number; the command line tool does
+// (mapper/alfalfa_main.cpp, through alfa_hw_queues_defaulted()).
+static int g_hw_queues_defaulted = 0;
 __attribute__((constructor)) static void alfa_default_hw_queues() {
     const char* e = getenv("ALFA_HW_QUEUES");
-    int n = e ? atoi(e) : 16;
-    if (n <= 0) return;
-    if (n > 32) n = 32;
-    char buf[8];
-    snprintf(buf, sizeof buf, "%d", n);
-    (void)setenv("GPU_MAX_HW_QUEUES", buf, 1);
+    if (e) {
+        int n = atoi(e);
+        if (n <= 0) return;
+        if (n > 32) n = 32;
+        char buf[8];
+        snprintf(buf, sizeof buf, "%d", n);
+        (void)setenv("GPU_MAX_HW_QUEUES", buf, 1);
+        return;
+    }
+    if (getenv("GPU_MAX_HW_QUEUES")) return;      // the host application or the operator has chosen
+    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    g_hw_queues_defaulted = 1;
 }
+extern "C" int alfa_hw_queues_defaulted(void) { return g_hw_queues_defaulted; }
 
 namespace alfa {
 
@@ -109,6 +119,17 @@ Ctx::~Ctx() {
     stream = nullptr;
 }
 
+// STREAM PRIORITIES ARE PROHIBITED HERE: every stream of a context is created with the default priority, and must stay so.
+// Round 2 tried a higher priority for `stream` (the seed kernels) than for the DP side chains and the C4 bench stopped making
+// progress ("the stream-priority hang").  The library's kernels never wait on each other (no spin loops,
+// no inter-workgroup flags; the only device-side waits are hipCUB's look-back scans, inside one in-order dispatch), so what can
+// fail to be satisfied is a CROSS-STREAM wait: join_sides() and the fill_ev / fork_ev edges put barrier packets on one stream
+// that wait for events of another.  With one priority level all those queues are scheduled round-robin and every wait is
+// eventually satisfied.  With two levels the waiting packet sits at the head of a HIGH-priority hardware queue, which the
+// scheduler keeps runnable in its strict upper band, while the signal has to come from a NORMAL-priority queue: HIP keeps a
+// pool of GPU_MAX_HW_QUEUES queues PER priority level (16 + 16 here, plus torch's), which oversubscribes the hardware queue
+// slots, and under oversubscription a lower band is only mapped when the upper band is idle -- it never is: priority inversion.
+// alfa_stream_priority_span() lets a test check the rule (tests/test_gpu_ksw.py).
 // The context is usable only when EVERY stream and event exists: a failure part-way tears down what was created, so the
 // next call starts from scratch instead of running on a half-built context.
 int Ctx::ensure(int dev) {
@@ -182,3 +203,26 @@ extern "C" int alfa_last_timing(alfa_timing* out) {
 }
 
 extern "C" void alfa_free(void* p) { free(p); }
+
+// lowest and highest HIP priority among the streams of the calling thread's context for `device` (they must be equal, see
+// Ctx::ensure)
+extern "C" int alfa_stream_priority_span(int device, int* lo, int* hi) {
+    if (!lo || !hi) return alfa::fail(ALFA_EINVAL, "null argument");
+    alfa::Ctx* cx = alfa::thread_ctx(device);
+    if (!cx) return ALFA_ENODEV;
+    int mn = 0, mx = 0;
+    bool first = true;
+    auto see = [&](hipStream_t st) -> hipError_t {
+        int p = 0;
+        hipError_t e = hipStreamGetPriority(st, &p);
+        if (e != hipSuccess) return e;
+        if (first) { mn = mx = p; first = false; }
+        mn = std::min(mn, p); mx = std::max(mx, p);
+        return hipSuccess;
+    };
+    ALFA_HIP(see(cx->stream));
+    ALFA_HIP(see(cx->up));
+    for (auto st : cx->side) ALFA_HIP(see(st));
+    *lo = mn; *hi = mx;
+    return ALFA_OK;
+}

@@ -1455,6 +1455,7 @@ struct alfa_dp_batch {
     alfa::PinBuf h_out, h_cig;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool launched = false;
+    bool ev1_pending = false;           // launched under lazy joins: ev1 is recorded at the fetch-time join
     double kernel_ms = 0;
     const alfa::Ctx* owner = nullptr;   // launch and fetch are ordered on the creating thread's streams: other threads are refused
 };
@@ -1900,7 +1901,11 @@ int launch_batch(alfa_dp_batch* b, Ctx* cx) {
     else if (b->mode == MODE_NW) launch_all<MODE_NW>(b, cx);
     else launch_all<MODE_GLOBAL>(b, cx);
     ALFA_HIP(hipGetLastError());
-    ALFA_HIP(hipEventRecord(b->ev1, st));
+    // with lazy joins the batch's kernels run on side streams that `st` has not waited for yet: an event recorded here would
+    // bracket almost none of them.  The closing event is then recorded at the fetch-time join (fetch_batch), so that
+    // kernel_ms spans the whole batch (and whatever else the stream ran in between: documented in include/alfa_hot.h)
+    b->ev1_pending = cx->lazy_join;
+    if (!b->ev1_pending) ALFA_HIP(hipEventRecord(b->ev1, st));
     b->launched = true;
     return ALFA_OK;
 }
@@ -1913,6 +1918,7 @@ int fetch_batch(alfa_dp_batch* b, Ctx* cx, void* out_host, const int* ids, std::
     hipStream_t st = cx->stream;
     int jrc = cx->join_sides();
     if (jrc) return jrc;
+    if (b->ev1_pending) { ALFA_HIP(hipEventRecord(b->ev1, st)); b->ev1_pending = false; }
     ALFA_HIP(hipMemcpyAsync(b->h_out.p, b->d_out.p, b->out_bytes, hipMemcpyDeviceToHost, st));
     if (b->mode == MODE_GLOBAL)
         ALFA_HIP(hipMemcpyAsync(b->h_cig.p, b->d_cig.p, 4 * (size_t)b->cig_words + 4 * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -2108,6 +2114,7 @@ int64_t alfa_dp_batch_giveups(alfa_dp_batch* b, int64_t* n_fast) {
 }
 double alfa_dp_batch_kernel_ms(const alfa_dp_batch* b) {
     if (!b || !b->launched || b->n == 0) return 0;
+    if (b->ev1_pending) return 0;      // launched under lazy joins and not fetched yet: no closing event exists (alfa_hot.h)
     float ms = 0;
     if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) { (void)hipGetLastError(); return b->kernel_ms; }
     return ms;

@@ -15,13 +15,13 @@ static int physical(int device) {
 }
 
 int main(int argc, char** argv) {
-    // libalfa_hot raises GPU_MAX_HW_QUEUES to 16 when it is loaded (device_ctx.hip), which pays when one caller overlaps large
-    // batches of every ksw kind.  The mapper's threads issue small synchronous batches: end to end it is the same with 4 or
-    // 16 queues (tools/gpu_queue_ab2.sh), and several mapper processes may share a GPU -- once the queues of all processes
-    // on a GPU exceed its hardware slots the driver time-slices them (this tool beside a 16-queue process: 1.6 -> 2.4 s per
-    // million reads).  So the tool goes back to HIP's default of 4 unless ALFA_HW_QUEUES says otherwise (8 is worth ~5 % on long
-    // reads: 1.93-2.05 -> 1.86-1.94 s per 50 000 reads, nothing on 250-bp reads); nothing has initialised HIP yet at this point.
-    if (!getenv("ALFA_HW_QUEUES")) (void)setenv("GPU_MAX_HW_QUEUES", "4", 1);
+    // When nobody has chosen a hardware-queue count, loading libalfa_hot installs 16 (device_ctx.hip), which pays when one
+    // caller overlaps large batches of every ksw kind.  The mapper's threads issue small synchronous batches, and several
+    // mapper processes may share a GPU -- once the queues of all processes on a GPU exceed its hardware slots the driver
+    // time-slices them -- so the tool replaces that default (and only that: a GPU_MAX_HW_QUEUES from the environment or an
+    // ALFA_HW_QUEUES request stands) with HIP's own default of 4.  Nothing has initialised HIP yet at this point, and the
+    // process is still single-threaded.  --stats prints the effective value.
+    if (alfa_hw_queues_defaulted()) (void)setenv("GPU_MAX_HW_QUEUES", "4", 1);
     // 16 workers build and drop reads, task copies and CIGAR vectors of 10-100 KiB all the time: keep such blocks in the heap
     // (glibc would mmap/munmap each one above 128 KiB and trim the heap top after frees; every fresh page then faults under the
     // address-space lock all threads share).  Long reads: map phase 1.7 -> 1.37 s per 50 000 reads.

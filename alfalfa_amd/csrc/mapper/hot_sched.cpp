@@ -42,12 +42,25 @@ alfa_ctx_switch:
 namespace alfa {
 
 static thread_local HotSched* tl_sched = nullptr;      // the scheduler whose fibers run on this thread
-// Fiber stacks come out of arenas (one mapping per batch of new fibers): adjacent stacks share a VMA and the kernel backs them
-// with huge pages -- a guard page below EVERY stack split the mapping into 4 KiB-paged islands and cost 17 % of the map phase
-// (1.40 -> 1.65 s per 10^6 reads).  So: one inaccessible page below each arena, and a canary word at the bottom of every stack
-// that is checked each time its fiber gives control back -- an overflow into the neighbour is reported, not silent.
-static constexpr size_t GUARD = 4096;
+// Fiber stacks come out of arenas (one mapping per batch of new fibers) so that the kernel can back them with huge pages -- a
+// guard page below EVERY stack split the mapping into 4 KiB-paged islands and cost 17 % of the map phase (1.40 -> 1.65 s per
+// 10^6 reads).  Layout: groups of GROUP stacks, each group preceded by an inaccessible gap; gaps and groups are multiples of
+// 2 MiB and the arena is 2 MiB-aligned, so every group is a VMA of whole huge pages (the gaps cost address space only).  An
+// overflow therefore runs at most GROUP - 1 stacks down before it faults, and each stack also carries a poisoned zone of
+// CANARY_WORDS words at its bottom that is checked every time its fiber gives control back: an overflow into a neighbour is
+// reported with the read's number, not silent (a frame would have to skip all 64 bytes to escape).
+// Depth: the deepest mapper path (map_paired -> paired_match45 -> process_lis_both -> extend_chain -> left_ext -> wait) holds
+// < 4 KiB of frames; the vectors live on the heap.  256 KiB per stack is 60x that.
+static constexpr size_t HUGE = (size_t)2 << 20;
+static constexpr int GROUP = 16;
+static constexpr int CANARY_WORDS = 8;
 static constexpr uint64_t CANARY = 0x616c66615f667372ull;
+static inline void poison(char* stack) { for (int k = 0; k < CANARY_WORDS; ++k) ((uint64_t*)stack)[k] = CANARY + (uint64_t)k; }
+static inline bool intact(const char* stack) {
+    uint64_t bad = 0;
+    for (int k = 0; k < CANARY_WORDS; ++k) bad |= ((const uint64_t*)stack)[k] ^ (CANARY + (uint64_t)k);
+    return bad == 0;
+}
 
 HotSched::HotSched(const HotOps& ops, const alfa_dp_params& prm, size_t stack_bytes) : ops_(ops), prm_(prm), stack_bytes_(stack_bytes) {}
 
@@ -253,17 +266,23 @@ void HotSched::run(int n, int max_fibers, const std::function<void(int)>& job) {
     const int nf = std::min(n, std::max(1, max_fibers));
     if ((int)fibers_.size() < nf) {
         const size_t add = (size_t)nf - fibers_.size();
-        const size_t bytes = GUARD + add * stack_bytes_;
-        char* base = (char*)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
-        if (base == (char*)MAP_FAILED) throw std::runtime_error("mmap of the fiber stacks failed");
-        (void)mprotect(base, GUARD, PROT_NONE);
-        (void)madvise(base + GUARD, bytes - GUARD, MADV_HUGEPAGE);
-        arenas_.push_back({base, bytes});
-        for (size_t k = 0; k < add; ++k) {
-            Fiber f;
-            f.stack = base + GUARD + k * stack_bytes_;
-            *(uint64_t*)f.stack = CANARY;
-            fibers_.push_back(f);
+        const size_t groups = (add + GROUP - 1) / GROUP;
+        const size_t gbytes = ((size_t)GROUP * stack_bytes_ + HUGE - 1) / HUGE * HUGE;     // one group of stacks, whole huge pages
+        const size_t bytes = HUGE + groups * (HUGE + gbytes);                             // alignment slack + (gap, group) pairs
+        char* raw = (char*)mmap(nullptr, bytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (raw == (char*)MAP_FAILED) throw std::runtime_error("mmap of the fiber stacks failed");
+        char* base = (char*)(((uintptr_t)raw + HUGE - 1) / HUGE * HUGE);
+        arenas_.push_back({raw, bytes});
+        for (size_t g = 0; g < groups; ++g) {
+            char* grp = base + g * (HUGE + gbytes) + HUGE;      // the gap in front of it stays PROT_NONE
+            if (mprotect(grp, gbytes, PROT_READ | PROT_WRITE) != 0) throw std::runtime_error("mprotect of the fiber stacks failed");
+            (void)madvise(grp, gbytes, MADV_HUGEPAGE);
+            for (int k = 0; k < GROUP && fibers_.size() < (size_t)nf; ++k) {
+                Fiber f;
+                f.stack = grp + (size_t)k * stack_bytes_;
+                poison(f.stack);
+                fibers_.push_back(f);
+            }
         }
     }
     tl_sched = this;
@@ -287,7 +306,7 @@ void HotSched::run(int n, int max_fibers, const std::function<void(int)>& job) {
             for (;;) {
                 current_ = fi;
                 alfa_ctx_switch(&main_sp_, f.sp);
-                if (*(const uint64_t*)f.stack != CANARY) {
+                if (!intact(f.stack)) {
                     fprintf(stderr, "ERROR: the stack of a mapping fiber overflowed (read %d; stack %zu bytes)\n", f.job, stack_bytes_);
                     abort();
                 }

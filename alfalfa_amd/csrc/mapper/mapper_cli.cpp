@@ -638,6 +638,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
             s.glob_tasks += x.glob_tasks; s.align_calls += x.align_calls; s.align_tasks += x.align_tasks; s.hot_seconds += x.hot_seconds;
         }
         fprintf(stderr, "#PHASES parse %.3f map %.3f print %.3f\n", t_parse, t_map, t_print);
+        fprintf(stderr, "#QUEUES GPU_MAX_HW_QUEUES %s\n", getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "unset");
         fprintf(stderr, "#STARTUP index_loaded %.3f device_ready %.3f workers_ready %.3f done %.3f (seconds since start)\n", t_index_ready,
                 t_device_ready, t_pool_ready, since_start());
         double sb = 0, sr = 0, sn = 0, mr = 0;

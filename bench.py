@@ -31,10 +31,15 @@ import time
 
 import numpy as np
 
-# libalfa_hot sets GPU_MAX_HW_QUEUES to ALFA_HW_QUEUES (default 16) when it is loaded (csrc/device_ctx.hip); torch may initialise
-# HIP before that, so the same is done here
-if os.environ.get("ALFA_HW_QUEUES", "16") != "0":
-    os.environ["GPU_MAX_HW_QUEUES"] = str(min(32, max(1, int(os.environ.get("ALFA_HW_QUEUES", "16")))))
+# hardware queues of the HIP runtime: the host chooses (include/alfa_hot.h: alfa_hw_queues_defaulted).  bench.py is the host
+# here and asks for ALFA_HW_QUEUES (default 16: the DP chains of overlapping batches run side by side) before torch or the
+# library initialise HIP; a GPU_MAX_HW_QUEUES already in the environment stands when ALFA_HW_QUEUES is not given.  The
+# effective value is printed in the line (`hw_queues`).
+if "ALFA_HW_QUEUES" in os.environ:
+    if os.environ["ALFA_HW_QUEUES"] != "0":
+        os.environ["GPU_MAX_HW_QUEUES"] = str(min(32, max(1, int(os.environ["ALFA_HW_QUEUES"]))))
+else:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -569,6 +574,7 @@ def main():
         "pcie_inclusive_reads_per_s": pcie["reads_per_s"],
         "pcie_inclusive": pcie,
         "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
         "timed_step_parity_vs_oracle": chk,
         "unit": "reads/s",
         "n_gpus": world,

@@ -224,7 +224,10 @@ int64_t alfa_dp_batch_cells(const alfa_dp_batch*);       /* inner-loop cells of 
 /* diagnostics: *n_fast = tasks of the batch that run in the band-in-registers kernel; returns how many ksw_extend tasks of a
  * launch gave up there because their band started to narrow and were finished by the moving-band code (synchronises; -1 on error) */
 int64_t alfa_dp_batch_giveups(alfa_dp_batch*, int64_t* n_fast);
-double  alfa_dp_batch_kernel_ms(const alfa_dp_batch*);   /* HIP-event time of the last launch's kernels (after fetch/sync) */
+/* HIP-event time of the last launch's kernels (after fetch/sync).  Under alfa_set_lazy_join the kernels run on side streams
+ * that are joined at fetch time: the closing event is recorded there, so the figure spans launch -> fetch-time join on the
+ * calling thread's stream (other work enqueued in between included), and it is 0 until the batch has been fetched. */
+double  alfa_dp_batch_kernel_ms(const alfa_dp_batch*);
 void    alfa_dp_batch_free(alfa_dp_batch*);
 
 typedef struct alfa_seed_plan alfa_seed_plan;
@@ -276,6 +279,15 @@ int  alfa_ksw_global_noalloc(const alfa_dp_params* p, const alfa_dev_task* d_tas
 void        alfa_free(void*);            /* every library-allocated host buffer */
 const char* alfa_last_error(void);       /* thread-local, human readable */
 int         alfa_device_count(void);     /* 0 when no HIP device is usable */
+/* Hardware queues of the HIP runtime (GPU_MAX_HW_QUEUES): the host application chooses.  Loading the library leaves a
+ * value that is already in the environment alone; only when the variable is absent does it install 16 (the DP chains of
+ * large batches run side by side on that many queues), and ALFA_HW_QUEUES=<n> is the explicit request that wins (0 = hands
+ * off).  Returns 1 when the library installed its default at load time, else 0.  No counterpart in the reference. */
+int         alfa_hw_queues_defaulted(void);
+/* diagnostics: lowest / highest HIP stream priority among the calling thread's streams for `device`.  The library creates all
+ * of them with the default priority and relies on it (cross-stream event waits between priority levels can starve: DESIGN.md
+ * section 5); a test checks *lo == *hi.  No counterpart in the reference. */
+int         alfa_stream_priority_span(int device, int* lo, int* hi);
 
 /* per-kernel timing of the calling thread's most recent batch call, measured with
  * HIP events on the library's own stream: kernel milliseconds, algorithmic work

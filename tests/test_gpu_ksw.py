@@ -131,3 +131,33 @@ def test_extend_large_scores_two_reduction_form(gpu, band):
     eo = O.orc_ksw_extend_batch(P, tasks)
     bad = np.nonzero(e != eo)[0]
     assert len(bad) == 0, [(int(i), len(pairs[i][0]), len(pairs[i][1]), ws[i], hs[i], e[i], eo[i]) for i in bad[:5]]
+
+
+def test_kernel_ms_under_lazy_join_spans_the_batch(gpu):
+    """alfa_dp_batch_kernel_ms under alfa_set_lazy_join: the closing event is recorded at the fetch-time join, so the figure
+    covers the batch's kernels (not the near-zero interval between two records on the caller's stream) and is 0 before the fetch."""
+    P = ffi.default_params()
+    pairs, ws, hs = dpgen.mapper_like_tasks(77, 4000, 3000, 0.1, 100)
+    tasks, keep = ffi.make_dp_tasks(pairs, ws, hs)
+    b = ffi.DpBatch(ffi.DP_NW, P, tasks, 0)
+    b.launch(); b.fetch()                      # warm-up
+    b.launch(); b.fetch()
+    plain = b.kernel_ms
+    assert plain > 0
+    ffi.set_lazy_join(0, True)
+    try:
+        b.launch()
+        assert b.kernel_ms == 0                # launched, side chains not joined yet: no closing event
+        b.fetch()
+        lazy = b.kernel_ms
+    finally:
+        ffi.set_lazy_join(0, False)
+    assert 0.8 * plain <= lazy <= 1.5 * plain + 0.2, (plain, lazy)
+
+
+def test_all_streams_of_a_context_share_one_priority(gpu):
+    """csrc/device_ctx.hip: stream priorities are prohibited (cross-priority event waits can starve)"""
+    import ctypes as C
+    lo, hi = C.c_int(0), C.c_int(0)
+    ffi.check(ffi.lib().alfa_stream_priority_span(0, C.byref(lo), C.byref(hi)))
+    assert lo.value == hi.value

@@ -118,3 +118,19 @@ def test_multi_gpu_worker_groups_keep_output_and_order(name):
     gold = M.golden_body(name)
     for gpus, threads in ((2, "4"), (3, "5"), (2, "2")):
         assert M.run_config(M.CPU_EXE, name, ["-t", threads, "--gpus", str(gpus)]) == gold, (gpus, threads)
+
+
+def test_fiber_stack_overflow_is_reported_not_silent():
+    """hot_sched.cpp: a mapping fiber that outgrows its stack is reported (poisoned zone at the bottom of every stack, checked at
+    each switch) or faults on the inaccessible gap in front of its group of stacks; a fiber that stays inside runs clean."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cpu_mapper")
+    ok = subprocess.run([exe, "--fiber-overflow-test", str(40 * 1024)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert ok.returncode == 0 and b"no overflow detected" in ok.stdout
+    # 64 KiB stacks: 100 KiB of frames runs into the neighbour below -> reported by the canary check (abort)
+    bad = subprocess.run([exe, "--fiber-overflow-test", str(100 * 1024)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert bad.returncode != 0
+    assert b"overflowed" in bad.stderr or bad.returncode in (-11, -7, -6, 139, 135, 134), (bad.returncode, bad.stderr[-300:])
+    # far beyond the group (16 stacks of 64 KiB = 1 MiB): must hit the inaccessible gap, i.e. a fault, never silent success
+    worse = subprocess.run([exe, "--fiber-overflow-test", str(4 << 20)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert worse.returncode != 0 and b"no overflow detected" not in worse.stdout

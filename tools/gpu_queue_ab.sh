@@ -9,10 +9,10 @@ print(sys.argv[1], "value", round(d["value"]), "ms/step", round(d["ms_per_step"]
 PY
 }
 for q in 4 8 16; do
-  GPU_MAX_HW_QUEUES=$q timeout -k 10 300 python -u bench.py --config c4 --steps 10 --e2e-reads 0 --no-cpu-baseline --align-tasks 1000 > gpurun_out/q_c4_$q.json 2>gpurun_out/q_c4_$q.err || { tail -n 20 gpurun_out/q_c4_$q.err; exit 1; }
+  ALFA_HW_QUEUES=$q timeout -k 10 300 python -u bench.py --config c4 --steps 10 --e2e-reads 0 --no-cpu-baseline --align-tasks 1000 > gpurun_out/q_c4_$q.json 2>gpurun_out/q_c4_$q.err || { tail -n 20 gpurun_out/q_c4_$q.err; exit 1; }
   show "c4 q=$q" gpurun_out/q_c4_$q.json
 done
 for q in 4 8 16; do
-  GPU_MAX_HW_QUEUES=$q timeout -k 10 300 python -u bench.py --steps 20 --e2e-reads 0 --no-cpu-baseline --align-tasks 1000 > gpurun_out/q_c3_$q.json 2>gpurun_out/q_c3_$q.err || { tail -n 20 gpurun_out/q_c3_$q.err; exit 1; }
+  ALFA_HW_QUEUES=$q timeout -k 10 300 python -u bench.py --steps 20 --e2e-reads 0 --no-cpu-baseline --align-tasks 1000 > gpurun_out/q_c3_$q.json 2>gpurun_out/q_c3_$q.err || { tail -n 20 gpurun_out/q_c3_$q.err; exit 1; }
   show "c3 q=$q" gpurun_out/q_c3_$q.json
 done
