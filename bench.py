@@ -135,6 +135,13 @@ def mapper_dp_tasks(workdir, index_prefix, reads, threads=8, device=0, extra=())
     subprocess.run([exe, "align", "-i", index_prefix, "-0", fq, "-o", os.path.join(workdir, "step.sam"), "-t", str(threads),
                     "--device", str(device)] + list(extra),
                    check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return load_task_log(prefix)
+
+
+def load_task_log(prefix):
+    """every DP task an `alfalfa_amd align` run with ALFA_TASK_LOG=prefix submitted: {kind: (ctypes DpTask array, keepalive)}"""
+    import glob
+    from alfalfa_amd import ffi
     hdrs, seqs = [], []
     for hf in sorted(glob.glob(prefix + ".*.hdr")):
         hdrs.append(np.fromfile(hf, np.int32).reshape(-1, 5))

@@ -232,3 +232,54 @@ def run_c5_paired(exe, d, threads="4", index_exe=None):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     return sam_body(out)
+
+
+# ---- C4 at size (BASELINE configs[3]): 100 Mbp iid reference (PRNG seed 2), reads of 2-10 kbp at 10 % error
+# (60/20/20), `-e 0.12`, index sparseness 12.  Deterministic inputs; the compiled reference's md5 is a fixture
+# (tests/golden/c4_md5.json, tools/make_c4_goldens.py).
+C4_ARGS = ["-e", "0.12"]
+C4_REF_LEN = 100000000
+C4_READS = 20000
+
+
+def c4_reference():
+    import numpy as np
+    import seqgen
+    return seqgen.ACGT[np.random.default_rng(2).integers(0, 4, C4_REF_LEN)]
+
+
+def c4_reads(ref_bytes, n=C4_READS, seed=404):
+    import numpy as np
+    import seqgen
+    return seqgen.sim_reads(np.random.default_rng(seed), ref_bytes, n, 2000, 10000, 0.10)
+
+
+def write_c4(d, n=C4_READS):
+    """writes c4.fa / c4.fq into d (once); returns (reference as uint8 array, reads)"""
+    ref = c4_reference()
+    refb = ref.tobytes()
+    reads = c4_reads(refb, n)
+    fa = os.path.join(d, "c4.fa")
+    if not os.path.exists(fa):
+        up = refb.upper()
+        with open(fa, "wb") as f:
+            f.write(b">chr1\n")
+            f.write(b"\n".join(up[i:i + 60] for i in range(0, len(up), 60)) + b"\n")
+    fq = os.path.join(d, "c4.fq")
+    if not os.path.exists(fq):
+        with open(fq, "wb") as f:
+            for i, r in enumerate(reads):
+                f.write(b"@r%d\n%s\n+\n%s\n" % (i, r.upper(), b"I" * len(r)))
+    return ref, reads
+
+
+def run_c4(exe, d, threads="16", index_args=(), env=None):
+    pre = os.path.join(d, "c4idx_%s" % os.path.basename(exe))
+    if not os.path.exists(pre + ".aux"):
+        subprocess.run([exe, "index", "-r", "c4.fa", "-p", pre, "-s", "12"] + list(index_args), cwd=d, check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+    out = os.path.join(d, "c4_%s.sam" % os.path.basename(exe))
+    p = subprocess.run([exe, "align", "-i", pre, "-0", "c4.fq", "-o", out, "-t", threads] + C4_ARGS, cwd=d, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return sam_body(out)

@@ -1,0 +1,133 @@
+"""C4 AT SIZE (BASELINE configs[3]): 100 Mbp iid reference (PRNG seed 2), index sparseness 12 built ON THE GPU
+(alfa_index_build_on_device), 20 000 reads of 2-10 kbp at 10 % error (60/20/20), `-e 0.12`.
+
+* seeds: the whole read set (40 000 strands, the sorted 10-mer-order path that such an index takes) -- size-independent
+  properties on every match (exact, right-maximal, left-maximal, in range, deterministic) + exact oracle parity, order
+  included, on a 600-read sample with the reference's per-read min_len / sparseQ (src/mapper.cpp:1226-1228, :533-536);
+* the command line tool end to end on the same reads against the md5 of the compiled reference's SAM
+  (tests/golden/c4_md5.json, tools/make_c4_goldens.py);
+* every DP task that run issued (ALFA_TASK_LOG), replayed through the C ABI: a sample of each ksw kind against the oracle,
+  all of them for ksw_nw == ksw_global's score.
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from alfalfa_amd import ffi
+import oracle_ffi as O
+import mapper_util as M
+import golden_util as G
+import seqgen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+K = 12
+ERR_PERCENT = 0.13          # -e 0.12 stores 0.13 (src/options.cpp:296)
+
+
+@pytest.fixture(scope="module")
+def c4(gpu):
+    d = G.tmpdir()
+    ref, reads = M.write_c4(d)
+    return d, ref, reads
+
+
+def test_c4_index_built_on_device_and_seeds_at_size(c4, gpu):
+    d, ref, reads = c4
+    refb = ref.tobytes()
+    ffi.index_build_on_device(0)
+    try:
+        hidx = ffi.HostIndex.build_mem(["chr1"], [refb], K=K)
+    finally:
+        ffi.index_build_on_device(-1)
+    host_built = ffi.HostIndex.build_mem(["chr1"], [refb], K=K)
+    a, b = hidx.arrays(), host_built.arrays()
+    for k in a:
+        if isinstance(a[k], np.ndarray):
+            assert np.array_equal(a[k], b[k]), k
+    del host_built, a, b
+    assert hidx.view.n == hidx.view.N // K and hidx.view.n > 8000000
+    didx = ffi.DeviceIndex(hidx, 0)
+    both = reads + [seqgen.revcomp(r) for r in reads]
+    prm = [seqgen.seed_params(K, len(r), ERR_PERCENT) for r in both]
+    q = ffi.make_seed_queries(both, [x for x, _ in prm], 10000, [y for _, y in prm])
+    plan = ffi.SeedPlan(didx, ffi.SEED_SMAM, q)
+    assert plan.sorted, "a 100 Mbp index must take the sorted (10-mer order) path"
+    plan.launch()
+    m, off = plan.fetch()
+    del plan
+    assert off[0] == 0 and off[-1] == len(m) and np.all(np.diff(off) >= 0)
+    assert len(m) > 2 * len(reads)
+    m2, off2 = didx.seed_batch(ffi.SEED_SMAM, q)                       # determinism, and the synchronous entry point
+    assert np.array_equal(off, off2) and np.array_equal(m, m2)
+    # every match: exact, inside read and text, at least min_len - K long, right-maximal and strictly left-maximal
+    owner = np.repeat(np.arange(len(both)), np.diff(off))
+    plen = np.array([len(r) for r in both], dtype=np.int64)
+    min_len = np.array([x for x, _ in prm], dtype=np.int64)
+    ln, qs, rs = m["len"].astype(np.int64), m["query"].astype(np.int64), m["ref"].astype(np.int64)
+    assert np.all(ln >= min_len[owner] - K) and np.all(qs >= 0) and np.all(qs + ln <= plen[owner]) and np.all(rs >= 0) and np.all(rs + ln <= len(refb))
+    cat = np.frombuffer(b"".join(both), dtype=np.uint8)
+    rstart = np.concatenate([[0], np.cumsum(plen)[:-1]])
+    tot = int(ln.sum())
+    within = np.arange(tot) - np.repeat(np.cumsum(ln) - ln, ln)
+    assert np.array_equal(cat[np.repeat(rstart[owner] + qs, ln) + within], ref[np.repeat(rs, ln) + within])
+    rq, rr = qs + ln, rs + ln
+    can = (rq < plen[owner]) & (rr < len(refb))
+    assert not np.any(cat[(rstart[owner] + rq)[can]] == ref[rr[can]])
+    can = (qs > 0) & (rs > 0)
+    assert not np.any(cat[(rstart[owner] + qs - 1)[can]] == ref[(rs - 1)[can]])
+    # exact parity with the oracle (order included) on a sample of 600 read strands
+    pick = np.random.default_rng(8).choice(len(both), 600, replace=False)
+    qs2 = ffi.make_seed_queries([both[i] for i in pick], [prm[i][0] for i in pick], 10000, [prm[i][1] for i in pick])
+    mo, oo = O.orc_seed_batch(hidx.view, ffi.SEED_SMAM, qs2)
+    for k, i in enumerate(pick):
+        assert np.array_equal(m[off[i]:off[i + 1]], mo[oo[k]:oo[k + 1]]), int(i)
+
+
+def test_c4_cli_vs_reference_md5_and_its_dp_tasks_vs_oracle(c4, gpu):
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    d, ref, reads = c4
+    gold = json.load(open(os.path.join(G.GOLD, "c4_md5.json")))
+    prefix = os.path.join(d, "c4tasks")
+    env = dict(os.environ, ALFA_TASK_LOG=prefix)
+    body = M.run_c4(M.GPU_EXE, d, threads="16", index_args=["--gpu-index"], env=env)
+    recs = [l for l in body.split(b"\n") if l and not l.startswith(b"@")]
+    assert len(recs) == gold["records"]
+    assert sum(1 for l in recs if not (int(l.split(b"\t")[1]) & 4)) == gold["mapped"]
+    assert M.md5(body) == gold["md5"]
+    # the DP tasks of that run
+    tk = bench.load_task_log(prefix)
+    P = ffi.default_params()
+    (te, _ke), (tn, _kn), (tg, _kg) = tk["extend"], tk["nw"], tk["global"]
+    assert len(te) > len(reads) and len(tn) > len(reads) and len(tg) > len(reads)
+    rng = np.random.default_rng(21)
+    ext = ffi.ksw_extend_batch(P, te)
+    nw = ffi.ksw_nw_batch(P, tn)
+    sg, cg, ng, og = ffi.ksw_global_batch(P, tg)
+
+    def sample(tasks, n):
+        idx = np.sort(rng.choice(len(tasks), min(n, len(tasks)), replace=False))
+        sub = (ffi.DpTask * len(idx))(*[tasks[int(i)] for i in idx])
+        return idx, sub
+    idx, sub = sample(te, 2500)
+    assert np.array_equal(ext[idx], O.orc_ksw_extend_batch(P, sub))
+    idx, sub = sample(tn, 4000)
+    assert np.array_equal(nw[idx], O.orc_ksw_nw_batch(P, sub))
+    idx, sub = sample(tg, 4000)
+    so, co, no, oo = O.orc_ksw_global_batch(P, sub)
+    assert np.array_equal(sg[idx], so)
+    for k, i in enumerate(idx):
+        t = tg[int(i)]
+        if t.tlen > t.qlen + t.w:
+            assert ng[i] == -1
+            continue
+        assert ng[i] == no[k] and np.array_equal(cg[og[i]:og[i] + ng[i]], co[oo[k]:oo[k] + no[k]]), int(i)
+    # size-independent: ksw_nw of every ksw_global task is ksw_global's score (src/ksw.c:544 vs :468)
+    assert np.array_equal(ffi.ksw_nw_batch(P, tg), sg)
