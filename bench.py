@@ -95,18 +95,94 @@ def simulate_batch(rng, ref, n, rlen, err):
 TASK_DTYPE = np.dtype([("query", "<u8"), ("target", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("h0", "<i4")])
 
 
-def usable_cores():
-    """host cores this process may use: the affinity mask, capped by OMP_NUM_THREADS when the box sets it (a GPU box shows
-    the whole machine in os.cpu_count() but gives a one-GPU job a share of it)"""
+def usable_cores(world=1):
+    """host cores the command line tools may use: the affinity mask, capped by the box's per-GPU share (OMP_NUM_THREADS when the
+    box sets it: a GPU box shows the whole machine in os.cpu_count() but gives a one-GPU job a share of it) times the GPUs of
+    the job.  torchrun exports OMP_NUM_THREADS=1 to its ranks when the variable was unset: that is not a share."""
     try:
         n = len(os.sched_getaffinity(0))
     except Exception:
         n = os.cpu_count() or 1
     try:
-        n = min(n, int(os.environ.get("OMP_NUM_THREADS", n)))
+        share = int(os.environ.get("OMP_NUM_THREADS", "0"))
     except ValueError:
-        pass
-    return max(1, n)
+        share = 0
+    if share <= 1:
+        share = 16 if world > 1 else n
+    return max(1, min(n, share * max(1, world)))
+
+
+def write_fastq(path, reads, mode="w"):
+    with open(path, mode + "b") as f:
+        for lo in range(0, len(reads), 50000):
+            f.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (lo + i, r, b"I" * len(r)) for i, r in enumerate(reads[lo:lo + 50000])))
+
+
+class GpuBusy:
+    """mean / max of the kernel driver's gpu_busy_percent per card while a command runs (sampled every 50 ms)"""
+    def __init__(self):
+        import glob
+        self.files = sorted(glob.glob("/sys/class/drm/card*/device/gpu_busy_percent"))
+        self.samples = {f: [] for f in self.files}
+        self._stop = False
+
+    def _loop(self):
+        while not self._stop:
+            for f in self.files:
+                try:
+                    self.samples[f].append(float(open(f).read().strip()))
+                except Exception:
+                    pass
+            time.sleep(0.05)
+
+    def __enter__(self):
+        import threading
+        self._t = threading.Thread(target=self._loop, daemon=True)
+        self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        self._t.join()
+
+    def summary(self):
+        out = {}
+        for f, v in self.samples.items():
+            if v and max(v) > 0:
+                out[f.split("/")[4]] = {"mean": round(sum(v) / len(v), 1), "max": max(v), "samples": len(v)}
+        return out or None
+
+
+def run_cli(exe, index_prefix, fq, out, threads, extra=(), gpus=None, stats=False):
+    """one `align` run of a command line tool: (wall seconds, return code, stderr text, per-GPU busy)"""
+    import subprocess
+    cmd = [exe, "align", "-i", index_prefix, "-0", fq, "-o", out, "-t", str(threads)] + list(extra)
+    if gpus is not None:
+        cmd += ["--gpus", str(gpus)]
+    if stats:
+        cmd += ["--stats"]
+    with GpuBusy() as gb:
+        t0 = time.perf_counter()
+        pr = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        dt = time.perf_counter() - t0
+    return dt, pr.returncode, pr.stderr.decode(errors="replace"), gb.summary()
+
+
+def sam_record_md5(path, n=None):
+    """md5 over the first n alignment records (all when n is None); header lines excluded.  With the default -a 1 a read
+    has exactly one record and output is in input order, so the first n records belong to the first n reads."""
+    import hashlib
+    h = hashlib.md5()
+    k = 0
+    with open(path, "rb") as f:
+        for line in f:
+            if line.startswith(b"@"):
+                continue
+            if n is not None and k >= n:
+                break
+            h.update(line)
+            k += 1
+    return h.hexdigest(), k
 
 
 def simulate_long(rng, ref_bytes, n, lo, hi, err):
@@ -185,10 +261,14 @@ def whole_job_value(batch, steps, world, elapsed):
 
 
 def dist_selftest(args, rank, world):
-    """CPU rehearsal of the N>1 control flow (tests/test_bench_dist.py, gloo): shard -> barrier -> MAX -> rank 0 reports"""
+    """CPU rehearsal of the N>1 control flow (tests/test_bench_dist.py, gloo): shard -> barrier -> MAX -> rank 0 reports; then
+    the hand-off around the end-to-end leg: the other ranks park in a CPU-group barrier while rank 0 runs the command line
+    tool with --gpus N (here the host mapper bound to the oracle, tests/_cpu_mapper, on the lambda example: N worker groups)
+    and reports mapped_reads_per_s as `value`."""
     import zlib
     import torch
     import torch.distributed as dist
+    cpu_group = dist.new_group(backend="gloo")
     ref = make_reference(200000, 1)
     fw, _, _, _ = simulate_batch(rank_rng(rank), ref, 64, 100, 0.02)
     crc = zlib.crc32(b"".join(fw))
@@ -196,9 +276,25 @@ def dist_selftest(args, rank, world):
     elapsed = max_over_ranks(0.25 * (rank + 1), world, "cpu")
     sums = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(sums, torch.tensor([crc], dtype=torch.int64))
-    if rank == 0:
-        print(json.dumps({"n_gpus": world, "elapsed": elapsed, "value": whole_job_value(64, args.steps, world, elapsed),
-                          "scaling": "weak", "shard_crc": [int(x.item()) for x in sums]}))
+    if rank != 0:
+        dist.barrier(group=cpu_group)
+        dist.barrier(group=cpu_group)
+        dist.destroy_process_group()
+        return
+    import golden_util as G
+    import mapper_util as M
+    dist.barrier(group=cpu_group)
+    d = M.workdir()
+    pre = os.path.join(d, "selftest_idx")
+    import subprocess
+    subprocess.run([M.CPU_EXE, "index", "-r", "reference.fasta", "-p", pre, "-s", "12"], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    outp = os.path.join(d, "selftest.sam")
+    dt, rcode, _err, _busy = run_cli(M.CPU_EXE, pre, os.path.join(d, "454reads.fq"), outp, 2 * world, [], gpus=world)
+    dist.barrier(group=cpu_group)
+    mapped = 100 / dt if rcode == 0 else None
+    print(json.dumps({"n_gpus": world, "elapsed": elapsed, "replay_reads_per_s": whole_job_value(64, args.steps, world, elapsed),
+                      "value": mapped, "mapped_reads_per_s": mapped, "sam_md5": M.md5(M.sam_body(outp)), "golden_md5": M.golden_md5("454_s12"),
+                      "scaling": "weak", "shard_crc": [int(x.item()) for x in sums]}))
     dist.destroy_process_group()
 
 
@@ -215,7 +311,9 @@ def main():
     ap.add_argument("--sparseness", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20000)
-    ap.add_argument("--e2e-reads", type=int, default=-1, help="reads for the end-to-end command line comparison (0 = skip; default 1000000 for c3, 20000 for c4)")
+    ap.add_argument("--e2e-reads", type=int, default=-1, help="reads of the end-to-end (headline) run: default steps x batch x GPUs; 0 = skip, value is then the replay figure")
+    ap.add_argument("--cpu-e2e-reads", type=int, default=-1, help="reads the compiled reference maps for cpu_baseline (a prefix of the same FASTQ; default min(e2e reads, 1000000 for c3 / 20000 for c4))")
+    ap.add_argument("--no-c4", action="store_true", help="default (c3) run: do not append the C4 block (a second bench.py run with --config c4)")
     ap.add_argument("--e2e-threads", type=int, default=0, help="threads of both command line tools (default: min(usable host cores, 214))")
     ap.add_argument("--align-tasks", type=int, default=50000, help="mate-rescue shaped ksw_align tasks for the informative ksw_align section")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for --dist-selftest)")
@@ -226,16 +324,34 @@ def main():
     args.ref_len = args.ref_len or (100000000 if c4 else 5000000)
     if c4:
         args.err = 0.10
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.e2e_reads < 0:
-        args.e2e_reads = 20000 if c4 else 1000000
-    cores = usable_cores()
+        args.e2e_reads = args.steps * args.batch * world        # the K timed steps of the headline: K batches per GPU, FASTQ -> SAM
+    if args.cpu_e2e_reads < 0:
+        args.cpu_e2e_reads = min(args.e2e_reads, 20000 if c4 else 1000000)
+    cores = usable_cores(world)
     if args.e2e_threads <= 0:
         args.e2e_threads = min(cores, 214)       # reference: bpCount = threads * 10^7 is an int (src/main.cpp:116)
     cli_extra = ["-e", "0.12"] if c4 else []     # the default 0.08 sends most 10 %-error reads through rescue
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ---- the C4 block (BASELINE configs[3], the configuration the 1/2/4/8 metric is quoted on) of the default line: at N = 1
+    # the whole line of a second run of this script with --config c4 (replay, rooflines, end to end, cpu_baseline), made BEFORE
+    # this process touches the GPU (two processes with 16 hardware queues each would time-slice); at N > 1 the end-to-end
+    # figure on N GPUs (c4_end_to_end, after the C3 legs)
+    c4_block = None
+    if not c4 and not args.no_c4 and world == 1 and not args.dist_selftest:
+        import subprocess
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", "c4", "--steps", "10", "--warmup", "2", "--align-tasks", "0"]
+            if args.no_cpu_baseline:
+                cmd.append("--no-cpu-baseline")
+            pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            line = [l for l in pr.stdout.decode().split("\n") if l.startswith("{")]
+            c4_block = json.loads(line[-1]) if line else {"error": pr.stderr.decode()[-500:]}
+        except Exception as e:   # the C4 block never fails the C3 line
+            c4_block = {"error": repr(e)}
     import torch
     import torch.distributed as dist
     if args.dist_selftest:
@@ -244,9 +360,13 @@ def main():
         return dist_selftest(args, rank, world)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group(args.backend, rank=rank, world_size=world)
+    # hand-off barriers around the end-to-end leg go through a CPU (gloo) group: a rank parked in an RCCL barrier spins in a
+    # kernel on its GPU, which would sit on the GPUs the command line tool is being measured on
+    cpu_group = dist.new_group(backend="gloo") if world > 1 else None
     dev = local_rank if world > 1 else 0
+    if os.environ.get("ALFA_ALIAS_DEVICES") and torch.cuda.is_available():
+        dev %= torch.cuda.device_count()         # rehearsal of N ranks on fewer cards (tests/test_gpu_mapper.py; use --backend gloo)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libalfa_hot has no CPU fallback")
     torch.cuda.set_device(dev)
@@ -390,8 +510,13 @@ def main():
                     "the query/task arrays is outside); dominated by host packing"}
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        # the end-to-end leg runs the command line tool on every GPU of the job (rank 0 starts it): give the memory back, wait
+        del steps, timed, sample
+        import gc
+        gc.collect()
+        dist.barrier(group=cpu_group)
+        dist.barrier(group=cpu_group)
+        dist.destroy_process_group()
         return
 
     # ---- algorithmic bytes of the dominant kernel (SURVEY 8d census, counted by the oracle on a sample)
@@ -466,44 +591,78 @@ def main():
                "sample": "%d reads (both strands seeded + their DP tasks) of step 0, oracle/liboracle.so, 1 thread" % nsamp,
                "seed_reads_per_s": nsamp / tseed, "dp_gcups": cpu_cells / max(tcpu - tseed, 1e-9) / 1e9}
 
-    # ---- end-to-end wall clock of the command line tools (FASTQ in -> SAM out, index load included): informative only,
-    # never `value`.  The reference executable compiled from /root/reference (oracle/_ref/alfalfa) travels with the tree.
+    # ---- THE HEADLINE (BASELINE's metric): mapped reads/s of the whole job, FASTQ in -> SAM out, through the
+    # product command line tool on all N GPUs of the job (`align --gpus N -t T`: reads sharded over the GPUs, index replicated,
+    # output gathered in input order; the reference's loop src/main.cpp:106-148).  The K timed steps are K batches per GPU,
+    # i.e. steps x batch x N reads in one FASTQ; the W warm-up steps are an untimed run of the tool on W batches.  Index load
+    # and HIP start-up are inside the timed interval.  Rank 0 starts the tool; the other ranks have freed their GPUs and wait.
     e2e = None
-    if args.e2e_reads > 0 and world == 1:
-        import hashlib
-        import subprocess
-        if c4:
-            er, _ = simulate_long(np.random.default_rng(77), ref_bytes, args.e2e_reads, 2000, 10000, args.err)
-        else:
-            er, _, _, _ = simulate_batch(np.random.default_rng(77), ref, args.e2e_reads, args.read_len, args.err)
+    gpu_exe = os.path.join(ROOT, "alfalfa_amd", "alfalfa_amd")
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "alfalfa")
+    if args.e2e_reads > 0:
+        erng = np.random.default_rng(77)
         fq = os.path.join(workdir, "e2e.fq")
-        with open(fq, "w") as f:
-            for i, r in enumerate(er):
-                f.write("@r%d\n%s\n+\n%s\n" % (i, r.decode(), "I" * len(r)))
-        e2e = {"reads": args.e2e_reads, "threads": args.e2e_threads}
-        for name, exe in (("alfalfa_amd_gpu", os.path.join(ROOT, "alfalfa_amd", "alfalfa_amd")),
-                          ("reference_cpu", os.path.join(ROOT, "oracle", "_ref", "alfalfa"))):
-            if not os.path.exists(exe):
-                continue
-            outp = os.path.join(workdir, name + ".sam")
-            tt = time.perf_counter()
-            pr = subprocess.run([exe, "align", "-i", index_prefix, "-0", fq, "-o", outp, "-t", str(args.e2e_threads)] + cli_extra,
-                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            dt = time.perf_counter() - tt
-            body = b"\n".join(l for l in open(outp, "rb").read().split(b"\n") if not l.startswith(b"@PG"))
-            e2e[name] = {"seconds": dt, "reads_per_s": args.e2e_reads / dt, "rc": pr.returncode, "sam_md5": hashlib.md5(body).hexdigest()}
-        if "reference_cpu" in e2e and "alfalfa_amd_gpu" in e2e:
-            e2e["sam_identical"] = e2e["reference_cpu"]["sam_md5"] == e2e["alfalfa_amd_gpu"]["sam_md5"]
+        open(fq, "wb").close()
+        done_reads = 0
+        while done_reads < args.e2e_reads:               # in chunks: the simulator holds a float per base
+            nchunk = min(200000 if not c4 else 20000, args.e2e_reads - done_reads)
+            if c4:
+                er, _ = simulate_long(erng, ref_bytes, nchunk, 2000, 10000, args.err)
+            else:
+                er, _, _, _ = simulate_batch(erng, ref, nchunk, args.read_len, args.err)
+            with open(fq, "ab") as f:
+                for lo in range(0, nchunk, 50000):
+                    f.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (done_reads + lo + i, r, b"I" * len(r)) for i, r in enumerate(er[lo:lo + 50000])))
+            done_reads += nchunk
+            del er
+        e2e = {"reads": args.e2e_reads, "threads": args.e2e_threads, "gpus": world}
+        if world > 1:
+            dist.barrier(group=cpu_group)                 # every other rank has released its GPU
+        if os.path.exists(gpu_exe):
+            outp = os.path.join(workdir, "alfalfa_amd_gpu.sam")
+            if args.warmup > 0:                           # W untimed warm-up batches through the same tool
+                wfq = os.path.join(workdir, "warm.fq")
+                nwarm = min(args.e2e_reads, args.warmup * args.batch)
+                with open(fq, "rb") as f, open(wfq, "wb") as g:
+                    for _ in range(4 * nwarm):
+                        g.write(f.readline())
+                run_cli(gpu_exe, index_prefix, wfq, os.path.join(workdir, "warm.sam"), args.e2e_threads, cli_extra, gpus=world)
+            dt, rcode, err_txt, busy = run_cli(gpu_exe, index_prefix, fq, outp, args.e2e_threads, cli_extra, gpus=world, stats=True)
+            md5_all, nrec = sam_record_md5(outp)
+            e2e["alfalfa_amd_gpu"] = {"seconds": dt, "reads_per_s": args.e2e_reads / dt, "rc": rcode, "records": nrec, "sam_md5": md5_all,
+                                      "gpu_busy_percent": busy,
+                                      "stats": [l for l in err_txt.split("\n") if l.startswith("#")]}
+        if world > 1:
+            dist.barrier(group=cpu_group)
+        if os.path.exists(ref_exe) and world == 1 and not args.no_cpu_baseline and args.cpu_e2e_reads > 0:
+            ncpu = min(args.cpu_e2e_reads, args.e2e_reads)
+            cfq = fq
+            if ncpu < args.e2e_reads:
+                cfq = os.path.join(workdir, "cpu.fq")
+                with open(fq, "rb") as f, open(cfq, "wb") as g:
+                    for _ in range(4 * ncpu):
+                        g.write(f.readline())
+            outp = os.path.join(workdir, "reference_cpu.sam")
+            dt, rcode, _err, _busy = run_cli(ref_exe, index_prefix, cfq, outp, args.e2e_threads, cli_extra)
+            md5_ref, nrec = sam_record_md5(outp)
+            e2e["reference_cpu"] = {"seconds": dt, "reads": ncpu, "reads_per_s": ncpu / dt, "rc": rcode, "records": nrec, "sam_md5": md5_ref}
+            if "alfalfa_amd_gpu" in e2e:
+                md5_gpu_prefix, _n = sam_record_md5(os.path.join(workdir, "alfalfa_amd_gpu.sam"), ncpu)
+                e2e["sam_identical"] = md5_ref == md5_gpu_prefix and nrec == ncpu
+                e2e["sam_identical_on"] = "the first %d reads (all that the reference mapped)" % ncpu
+    elif world > 1:
+        dist.barrier(group=cpu_group)
+        dist.barrier(group=cpu_group)
 
     # the baseline the north star asks for: the reference's own CPU path, multithreaded on this box's host cores.  It can
-    # only be timed as the whole command line (it has no hot-path-only mode), on the bounded sample of --e2e-reads reads;
+    # only be timed as the whole command line (it has no hot-path-only mode), on a bounded prefix of the same FASTQ;
     # the scalar port of the hot path alone (1 core) stays beside it.
     if e2e and e2e.get("reference_cpu", {}).get("rc") == 0:
         port = cpu
         cpu = {"value": e2e["reference_cpu"]["reads_per_s"], "unit": "reads/s", "cores": args.e2e_threads, "kind": "reference",
                "host_cores_usable": cores, "host_cpu_count": os.cpu_count(),
                "sample": "%d reads of the same workload through the compiled reference (oracle/_ref/alfalfa align -t %d), whole command "
-                         "line FASTQ -> SAM, %.1f s wall" % (args.e2e_reads, args.e2e_threads, e2e["reference_cpu"]["seconds"]),
+                         "line FASTQ -> SAM, %.1f s wall" % (e2e["reference_cpu"]["reads"], args.e2e_threads, e2e["reference_cpu"]["seconds"]),
                "hot_path_port_1core": port}
     # ---- ksw_align (mate rescue): not part of `value`; kernel time of one batch of rescue-shaped tasks
     # (150-bp mate with 3 % substitutions placed in a window of 2-3 mate lengths + 200, the mapper's penalties and xtra)
@@ -569,15 +728,32 @@ def main():
     except Exception:
         occupancy = None
     e2e_gpu = (e2e or {}).get("alfalfa_amd_gpu", {})
+    replay_value = whole_job_value(args.batch, args.steps, world, elapsed)
+    mapped = e2e_gpu.get("reads_per_s") if e2e_gpu.get("rc") == 0 else None
+    # ---- the C4 block (BASELINE configs[3], the configuration the 1/2/4/8 metric is quoted on): at N = 1 the whole line of a
+    # second run with --config c4 (replay, rooflines, end to end, cpu_baseline); at N > 1 the end-to-end figure on N GPUs
+    if not c4 and not args.no_c4 and world > 1:
+        try:
+            c4_block = c4_end_to_end(world, args.e2e_threads, dev)
+        except Exception as e:   # the C4 block never fails the C3 line
+            c4_block = {"error": repr(e)}
     out = {
-        "metric": "mapped reads/sec (hot path: SMAM seeds both strands + banded DP) + banded-DP GCUPS",
-        "value": whole_job_value(args.batch, args.steps, world, elapsed),
-        "value_is": "hot-path replay: kernel launches over batches already packed and resident in HBM (no H2D of reads/tasks, no "
-                    "D2H of results, no host chaining between DP rounds); NOT comparable with cpu_baseline, which is a whole "
-                    "command line -- compare mapped_reads_per_s with cpu_baseline.value",
-        "mapped_reads_per_s": e2e_gpu.get("reads_per_s"),
-        "mapped_reads_per_s_is": "SURVEY 8d: FASTQ in -> SAM out through alfalfa_amd align -t %d (index load and HIP start-up included), "
-                                 "SAM identical to the reference: %s" % (args.e2e_threads, (e2e or {}).get("sam_identical")),
+        "metric": "mapped reads/sec (whole node, FASTQ -> SAM, SAM byte-identical to the reference) + banded-DP GCUPS",
+        "value": mapped if mapped else replay_value,
+        "value_is": ("mapped reads/s of the whole job: %d reads (steps x batch x GPUs) FASTQ in -> SAM out through `alfalfa_amd align --gpus %d "
+                     "-t %d`, index load and HIP start-up included; compare with cpu_baseline.value (the compiled reference, same "
+                     "thread count, same box).  The kernels-only figure is replay_reads_per_s" % (args.e2e_reads, world, args.e2e_threads))
+                    if mapped else
+                    "hot-path replay (no end-to-end run was made: --e2e-reads 0 or the tool is missing): kernel launches over resident batches",
+        "mapped_reads_per_s": mapped,
+        "mapped_reads_per_s_is": "SURVEY 8d: FASTQ in -> SAM out through alfalfa_amd align --gpus %d -t %d (index load and HIP start-up included), "
+                                 "SAM identical to the reference: %s" % (world, args.e2e_threads, (e2e or {}).get("sam_identical")),
+        "replay_reads_per_s": replay_value,
+        "replay_is": "hot-path replay: kernel launches over batches already packed and resident in HBM (no H2D of reads/tasks, no D2H "
+                     "of results, no host chaining between DP rounds), %d steps of %d reads per GPU, %.3f ms per step; what the "
+                     "rooflines below are measured on.  NOT comparable with cpu_baseline" % (args.steps, args.batch, elapsed / args.steps * 1e3),
+        "replay_ms_per_step": elapsed / args.steps * 1e3,
+        "c4": c4_block,
         "pcie_inclusive_reads_per_s": pcie["reads_per_s"],
         "pcie_inclusive": pcie,
         "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
@@ -587,7 +763,8 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": (e2e_gpu["seconds"] / args.steps * 1e3) if mapped else elapsed / args.steps * 1e3,
+        "ms_per_step_is": "end-to-end seconds / steps (a step = one batch per GPU through the whole tool)" if mapped else "replay",
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -655,6 +832,38 @@ def main():
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def c4_end_to_end(world, threads, dev):
+    """BASELINE configs[3] end to end on `world` GPUs: 100 Mbp reference (seed 2), index built on the GPU, 20 000 reads of
+    2-10 kbp at 10 % per GPU, `alfalfa_amd align -e 0.12 --gpus world -t threads`: mapped reads/s of the whole job"""
+    import tempfile
+    from alfalfa_amd import ffi
+    wd = tempfile.mkdtemp(prefix="alfa_bench_c4_")
+    ref = make_reference(100000000, 2)
+    refb = ref.tobytes()
+    ffi.index_build_on_device(dev)
+    try:
+        hidx = ffi.HostIndex.build_mem(["chr1"], [refb], K=12)
+    finally:
+        ffi.index_build_on_device(-1)
+    pre = os.path.join(wd, "idx")
+    hidx.save(pre)
+    del hidx
+    n = 20000 * world
+    fq = os.path.join(wd, "c4.fq")
+    open(fq, "wb").close()
+    rng = np.random.default_rng(78)
+    for lo in range(0, n, 20000):
+        er, _ = simulate_long(rng, refb, min(20000, n - lo), 2000, 10000, 0.10)
+        with open(fq, "ab") as f:
+            f.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (lo + i, r, b"I" * len(r)) for i, r in enumerate(er)))
+    exe = os.path.join(ROOT, "alfalfa_amd", "alfalfa_amd")
+    dt, rcode, err_txt, busy = run_cli(exe, pre, fq, os.path.join(wd, "c4.sam"), threads, ["-e", "0.12"], gpus=world, stats=True)
+    md5_all, nrec = sam_record_md5(os.path.join(wd, "c4.sam"))
+    return {"workload": "BASELINE configs[3]: 100 Mbp iid reference, %d reads of 2-10 kbp at 10 %% error, -e 0.12, K=12" % n,
+            "n_gpus": world, "threads": threads, "mapped_reads_per_s": n / dt if rcode == 0 else None, "seconds": dt, "rc": rcode,
+            "records": nrec, "sam_md5": md5_all, "gpu_busy_percent": busy, "stats": [l for l in err_txt.split("\n") if l.startswith("#")]}
 
 
 def _align_ms(params, tasks):

@@ -80,3 +80,27 @@ def test_gpu_mapper_two_device_contexts(gpu):
             assert M.md5(body) == M.golden_md5(name), name
     finally:
         del os.environ["ALFA_ALIAS_DEVICES"]
+
+
+def test_bench_two_ranks_report_mapped_reads_per_s(gpu):
+    """bench.py --gpus 2 under torchrun, rehearsed on this one-GPU box (both ranks and both worker groups of the tool aliased
+    onto device 0, gloo instead of RCCL: RCCL refuses two ranks on one card): the line's `value` is the mapped reads/s of
+    `alfalfa_amd align --gpus 2` over steps x batch x 2 reads, n_gpus = 2, and the replay figure stands beside it."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ALFA_ALIAS_DEVICES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29671", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "5000",
+           "--backend", "gloo", "--no-c4", "--no-cpu-baseline", "--align-tasks", "0"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
+    assert out["mapped_reads_per_s"] and out["value"] == out["mapped_reads_per_s"]
+    e = out["end_to_end_cli"]
+    assert e["reads"] == 2 * 5000 * 2 and e["gpus"] == 2 and e["alfalfa_amd_gpu"]["rc"] == 0 and e["alfalfa_amd_gpu"]["records"] == e["reads"]
+    assert out["replay_reads_per_s"] > out["value"]
+    assert all(out["timed_step_parity_vs_oracle"].values())
