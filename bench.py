@@ -31,15 +31,14 @@ import time
 
 import numpy as np
 
-# hardware queues of the HIP runtime: the host chooses (include/alfa_hot.h: alfa_hw_queues_defaulted).  bench.py is the host
-# here and asks for ALFA_HW_QUEUES (default 16: the DP chains of overlapping batches run side by side) before torch or the
-# library initialise HIP; a GPU_MAX_HW_QUEUES already in the environment stands when ALFA_HW_QUEUES is not given.  The
-# effective value is printed in the line (`hw_queues`).
-if "ALFA_HW_QUEUES" in os.environ:
-    if os.environ["ALFA_HW_QUEUES"] != "0":
-        os.environ["GPU_MAX_HW_QUEUES"] = str(min(32, max(1, int(os.environ["ALFA_HW_QUEUES"]))))
-else:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# hardware queues of the HIP runtime: the host chooses (include/alfa_hot.h: alfa_hw_queues_defaulted), and bench.py is the host
+# here.  Its replay legs overlap the DP chains of several resident batches, which wants 16 queues (C4 step 10.1 ms with the
+# box's default of 4, 6.6-7.9 with 16), so this process asks for ALFA_HW_QUEUES (default 16) before torch or the library
+# initialise HIP.  The command line tools it starts get the environment's ORIGINAL value back (run_cli): the product runs as
+# an operator would run it.  Both values are printed in the line (`hw_queues`, `hw_queues_cli`).
+_ORIG_HWQ = os.environ.get("GPU_MAX_HW_QUEUES")
+if os.environ.get("ALFA_HW_QUEUES", "16") != "0":
+    os.environ["GPU_MAX_HW_QUEUES"] = str(min(32, max(1, int(os.environ.get("ALFA_HW_QUEUES", "16")))))
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -161,9 +160,13 @@ def run_cli(exe, index_prefix, fq, out, threads, extra=(), gpus=None, stats=Fals
         cmd += ["--gpus", str(gpus)]
     if stats:
         cmd += ["--stats"]
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    if _ORIG_HWQ is not None:
+        env["GPU_MAX_HW_QUEUES"] = _ORIG_HWQ
     with GpuBusy() as gb:
         t0 = time.perf_counter()
-        pr = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        pr = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
         dt = time.perf_counter() - t0
     return dt, pr.returncode, pr.stderr.decode(errors="replace"), gb.summary()
 
@@ -758,6 +761,7 @@ def main():
         "pcie_inclusive": pcie,
         "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
         "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+        "hw_queues_cli": _ORIG_HWQ if _ORIG_HWQ is not None else "unset (the tool then takes 4)",
         "timed_step_parity_vs_oracle": chk,
         "unit": "reads/s",
         "n_gpus": world,
