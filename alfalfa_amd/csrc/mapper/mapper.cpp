@@ -1,7 +1,11 @@
 // mapper.cpp -- see mapper.h.  Host logic around the hot path with the reference's semantics.
 #include "mapper.h"
 
+#include "../map_core.h"
+
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -12,6 +16,8 @@
 #include <type_traits>
 
 namespace alfa {
+
+struct Mapper_Lis_view { const std::vector<Match>* matches; bool fw; int score; };
 
 namespace {
 
@@ -335,7 +341,7 @@ static int covered_bases(std::vector<Match>& seeds) {
 }
 
 // calculateCandRegions src/mapper.cpp:1220-1267
-void Mapper::cand_regions(const Read& read, std::vector<Lis>& lis, double errorPercent) {
+void Mapper::cand_regions(const Read& read, std::vector<Lis>& lis, double errorPercent, bool sortByScore) {
     const std::string& P = read.sequence;
     const std::string& Prc = read.rcSequence;
     const int Plength = (int)P.length();
@@ -408,7 +414,7 @@ void Mapper::cand_regions(const Read& read, std::vector<Lis>& lis, double errorP
             }
             fflush(rlog);
         }
-        std::sort(lis.begin(), lis.end(), [](const Lis& a, const Lis& b) { return a.score > b.score; });   // compIntervals :1114
+        if (sortByScore) std::sort(lis.begin(), lis.end(), [](const Lis& a, const Lis& b) { return a.score > b.score; });   // compIntervals :1114
     }
 }
 
@@ -703,9 +709,109 @@ void Mapper::process_lis(Read& read, const std::vector<Lis>& lis, int editDist, 
     }
 }
 
+// ---- the trial loop through csrc/map_core.h (checker path, --core-trials): the same source the mapping kernel is compiled
+// from runs here with one "lane", its DP calls going through the scheduler like the mapper's own
+namespace {
+struct CoreEnv {
+    const RefIndex& idx; HotSched& hot; const Read& read; const std::vector<Mapper_Lis_view>* lis;
+    std::vector<mapcore::AlnOut> alns; std::vector<Match> seeds;
+    int lane() const { return 0; }
+    int lanes() const { return 1; }
+    void sync() const {}
+    bool load_region(mapcore::Work& W, int k, int& n, bool& fw, int& score) {
+        const Mapper_Lis_view& l = (*lis)[(size_t)k];
+        if (l.matches->size() > (size_t)mapcore::MEMBER_CAP) return false;
+        n = (int)l.matches->size(); fw = l.fw; score = l.score;
+        for (int i = 0; i < n; ++i) { W.mref[i] = (*l.matches)[i].ref; W.mq[i] = (*l.matches)[i].query; W.ml[i] = (*l.matches)[i].len; }
+        return true;
+    }
+    void chrom_bounds(int64_t pos, int64_t& cs, int64_t& ce) const { idx.chrom_bounds(pos, cs, ce); }
+    bool nw(bool fw, int qFrom, int qLen, int64_t tFrom, int tLen, int w, int& score) {
+        const std::string& P = fw ? read.sequence : read.rcSequence;
+        const char* S = idx.S();
+        std::vector<uint8_t> q((size_t)qLen), t((size_t)tLen);
+        for (int k = 0; k < qLen; ++k) q[k] = nt4((unsigned char)P[qFrom + k]);
+        for (int k = 0; k < tLen; ++k) t[k] = nt4((unsigned char)S[tFrom + k]);
+        int32_t s = 0;
+        hot.submit_nw(NwReq{alfa_dp_task{q.data(), t.data(), qLen, tLen, w, 0}, &s});
+        hot.wait();
+        score = s;
+        return true;
+    }
+    bool extend(bool fw, bool left, int qAnchor, int qLen, int64_t tAnchor, int tLen, int w, int h0, mapcore::ExtRes& r) {
+        const std::string& P = fw ? read.sequence : read.rcSequence;
+        const char* S = idx.S();
+        std::vector<uint8_t> q((size_t)qLen), t((size_t)std::max(tLen, 0));
+        for (int j = 0; j < qLen; ++j) q[j] = nt4((unsigned char)(left ? P[qAnchor - j - 1] : P[qAnchor + 1 + j]));
+        for (int j = 0; j < tLen; ++j) t[j] = nt4((unsigned char)(left ? S[tAnchor - j - 1] : S[tAnchor + 1 + j]));
+        alfa_extend_result e;
+        hot.submit_extend(ExtendReq{alfa_dp_task{q.data(), t.data(), qLen, tLen, w, h0}, &e});
+        hot.wait();
+        r.score = e.score; r.qle = e.qle; r.tle = e.tle; r.gtle = e.gtle; r.gscore = e.gscore; r.max_off = e.max_off;
+        return true;
+    }
+    void emit(int k, const mapcore::AlnOut& o) { if ((int)alns.size() <= k) alns.resize((size_t)k + 1); alns[(size_t)k] = o; }
+    void emit_seed(int k, int64_t ref, int32_t q, int32_t len) { if ((int)seeds.size() <= k) seeds.resize((size_t)k + 1); seeds[(size_t)k] = Match{ref, q, len}; }
+};
+}  // namespace
+
+std::atomic<long> g_core_done{0}, g_core_fallback{0};
+
+mapcore::Options core_options(const AlignOpt& o) {
+    mapcore::Options O;
+    O.match = o.match; O.mismatch = o.mismatch; O.openGap = o.openGap; O.extendGap = o.extendGap;
+    O.global = o.global ? 1 : 0; O.fixedBandSize = o.fixedBandSize; O.maxTrial = o.maxTrial; O.maxTrialBest = o.maxTrialBest ? 1 : 0;
+    O.maxAlnCount = o.maxAlnCount; O.rescue = o.rescue ? 1 : 0; O.errorPercent = o.errorPercent;
+    return O;
+}
+
+// what depends on the read length alone, in the reference's arithmetic (src/mapper.cpp:1224,1280-1287)
+mapcore::ReadParams core_read_params(const AlignOpt& o, int Plength) {
+    mapcore::ReadParams R;
+    R.plen = Plength;
+    R.editDist = (int)(o.errorPercent * Plength) + 1;
+    R.minScore = (int)(Plength * o.match + (o.mismatch - o.match) * R.editDist);
+    R.minCoverage = (int)(Plength * o.minCoverage);
+    R.minScore2 = std::max(0, (int)(Plength * o.match + (o.mismatch - o.match) * 0.2 * Plength));
+    R.minCoverage2 = (int)(Plength * 0.01);
+    return R;
+}
+
+// true: the read's alignments are in place (what unpaired_match's two passes would have produced); false: not handled
+bool Mapper::core_trials(Read& read, const std::vector<Lis>& lis) {
+    std::vector<Mapper_Lis_view> view;
+    view.reserve(lis.size());
+    for (const Lis& l : lis) view.push_back(Mapper_Lis_view{&l.matches, l.fw, l.score});
+    CoreEnv env{idx_, hot_, read, &view, {}, {}};
+    std::unique_ptr<mapcore::Work> W(new mapcore::Work());
+    if (lis.size() > (size_t)mapcore::REGION_CAP2) return false;
+    for (size_t k = 0; k < lis.size(); ++k) W->rscore[k] = lis[k].score;
+    const mapcore::Options O = core_options(opt_);
+    const mapcore::ReadParams R = core_read_params(opt_, (int)read.sequence.length());
+    if (mapcore::map_read(env, *W, O, R, (int)lis.size()) != mapcore::DONE) return false;
+    for (int k = 0; k < W->nAln; ++k) {
+        const mapcore::AlnOut& o = env.alns[(size_t)k];
+        Alignment* a = new Alignment();
+        a->refB = o.refB; a->refE = o.refE; a->qB = o.qB; a->qE = o.qE; a->alignmentScore = o.score;
+        if (!o.fw) a->flag |= 1u << 4;
+        a->refLength = (int)(o.refE - o.refB + 1);
+        a->chain.assign(env.seeds.begin() + o.chainFirst, env.seeds.begin() + o.chainFirst + o.chainCount);
+        read.alignments.push_back(a);
+    }
+    return true;
+}
+
 // unpairedMatch src/mapper.cpp:1269-1302
 void Mapper::unpaired_match(Read& read) {
     std::vector<Lis> lis;
+    if (opt_.coreTrials && read.alignments.empty()) {
+        cand_regions(read, lis, opt_.errorPercent, false);           // regions in creation order: map_core sorts them itself
+        if (core_trials(read, lis)) { g_core_done++; return; }
+        g_core_fallback++;
+        for (Alignment* a : read.alignments) delete a;
+        read.alignments.clear();
+        lis.clear();
+    }
     cand_regions(read, lis, opt_.errorPercent);
     if (lis.empty()) return;
     if (!read.alignments.empty()) {

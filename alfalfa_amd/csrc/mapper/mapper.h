@@ -8,7 +8,10 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+
 #include "../../../include/alfa_index.h"
+#include "../map_core.h"
 #include "hot_sched.h"
 
 namespace alfa {
@@ -35,6 +38,10 @@ struct AlignOpt {                 // align_opt, defaults of mapOptions_t::initOp
     int fixedBandSize = 100;
     int maxAlnCount = 5000;
     bool deviceRegions = false;   // --device-regions: identifyAndFilter + coveredBases run on the hot path's side
+    bool coreTrials = false;      // --core-trials (checker): the trial loop runs through csrc/map_core.h -- the code the mapping kernel is
+                                  // compiled from -- with the DP calls still going through the scheduler
+    bool deviceMap = true;        // reads are mapped by the hot path's whole-read entry point (alfa_map_reads_batch) when the binding has
+                                  // one; --host-trials switches it off
     void fill_m();                // align_opt::fill_m src/options.cpp:33-41
 };
 
@@ -124,7 +131,8 @@ class Mapper {
     void unpaired_match(Read& read);
     void seeds_both_strands(const std::string& P, const std::string& Prc, int min_len, std::vector<Match>& fw, std::vector<Match>& rc);
     void identify_and_filter(std::vector<Match>& matches, bool fw, int qLength, int editDist, std::vector<Lis>& lis);
-    void cand_regions(const Read& read, std::vector<Lis>& lis, double errorPercent);
+    void cand_regions(const Read& read, std::vector<Lis>& lis, double errorPercent, bool sortByScore = true);
+    bool core_trials(Read& read, const std::vector<Lis>& lis);
     void process_lis(Read& read, const std::vector<Lis>& lis, int editDist, int maxAlnCount, int minCoverage, int minScore);
     int extend_chain(const std::string& P, const std::vector<Match>& matches, int editDist, int minScore, int minCoverage,
                      int64_t chrStart, int64_t chrEnd, Read& read, bool fw, const Lis* first = nullptr);
@@ -162,5 +170,11 @@ class Mapper {
 };
 
 std::string sam_header(const RefIndex& idx, int argc, char** argv);
+
+// the trial loop's options and per-read parameters in map_core's form (the float arithmetic of src/mapper.cpp:1224,1280-1287
+// is done here, on the host)
+mapcore::Options core_options(const AlignOpt& o);
+mapcore::ReadParams core_read_params(const AlignOpt& o, int Plength);
+extern std::atomic<long> g_core_done, g_core_fallback;     // --core-trials / device mapping: reads done there, reads handed back
 
 }  // namespace alfa

@@ -118,6 +118,8 @@ bool parse(int argc, char** argv, Options& o) {
         else if (is(nullptr, "stats")) o.stats = true;
         else if (is(nullptr, "gpu-index")) o.gpuIndex = true;
         else if (is(nullptr, "device-regions")) o.aln.deviceRegions = true;
+        else if (is(nullptr, "core-trials")) o.aln.coreTrials = true;
+        else if (is(nullptr, "host-trials")) o.aln.deviceMap = false;
         else { fprintf(stderr, "ERROR: unknown option %s\n", a.c_str()); exit(1); }
     }
     if (o.command == "index") {
@@ -638,6 +640,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
             s.glob_tasks += x.glob_tasks; s.align_calls += x.align_calls; s.align_tasks += x.align_tasks; s.hot_seconds += x.hot_seconds;
         }
         fprintf(stderr, "#PHASES parse %.3f map %.3f print %.3f\n", t_parse, t_map, t_print);
+        fprintf(stderr, "#CORE reads_done %ld handed_back %ld\n", g_core_done.load(), g_core_fallback.load());
         fprintf(stderr, "#QUEUES GPU_MAX_HW_QUEUES %s\n", getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "unset");
         fprintf(stderr, "#STARTUP index_loaded %.3f device_ready %.3f workers_ready %.3f done %.3f (seconds since start)\n", t_index_ready,
                 t_device_ready, t_pool_ready, since_start());

@@ -350,7 +350,11 @@ def main():
             cmd = [sys.executable, os.path.abspath(__file__), "--config", "c4", "--steps", "10", "--warmup", "2", "--align-tasks", "0"]
             if args.no_cpu_baseline:
                 cmd.append("--no-cpu-baseline")
-            pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            cenv = dict(os.environ)
+            cenv.pop("GPU_MAX_HW_QUEUES", None)
+            if _ORIG_HWQ is not None:
+                cenv["GPU_MAX_HW_QUEUES"] = _ORIG_HWQ          # the child makes the same choice from the same starting point
+            pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=cenv)
             line = [l for l in pr.stdout.decode().split("\n") if l.startswith("{")]
             c4_block = json.loads(line[-1]) if line else {"error": pr.stderr.decode()[-500:]}
         except Exception as e:   # the C4 block never fails the C3 line

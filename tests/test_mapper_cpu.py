@@ -134,3 +134,32 @@ def test_fiber_stack_overflow_is_reported_not_silent():
     # far beyond the group (16 stacks of 64 KiB = 1 MiB): must hit the inaccessible gap, i.e. a fault, never silent success
     worse = subprocess.run([exe, "--fiber-overflow-test", str(4 << 20)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert worse.returncode != 0 and b"no overflow detected" not in worse.stdout
+
+
+# ---- csrc/map_core.h: the source of the mapping kernel's trial loop, compiled here with g++ and driven by the host mapper
+# (`--core-trials`) with the oracle's DP: same SAM as the reference
+@pytest.mark.parametrize("name", ["454_s12", "454_s1", "pe_s12", "454_s1_local", "454_s12_e12", "454_s1_a5", "pe_s12_rescue_a3"])
+def test_map_core_trial_loop_matches_reference_sam(name):
+    body = M.run_config(M.CPU_EXE, name, ["--core-trials", "-t", "2"])
+    assert M.md5(body) == M.golden_md5(name)
+
+
+@pytest.mark.parametrize("name", ["synse_default", "synse_scores", "synse_band_trials", "synse_minlen", "synse_mem_local"])
+def test_map_core_trial_loop_option_sweep(name):
+    body = M.run_synth_single(M.CPU_EXE, name, ["--core-trials", "-t", "4"])
+    assert M.md5(body) == M.synth_md5(name)
+
+
+def test_map_core_trial_loop_paired_and_its_hand_backs():
+    import re
+    body, err = M.run_synth(M.CPU_EXE, "synpe_rescue", ["--core-trials", "-t", "4", "--stats"])
+    assert M.md5(body) == M.synth_md5("synpe_rescue")
+    m = re.search(r"#CORE reads_done (\d+) handed_back (\d+)", err)
+    assert m and int(m.group(1)) > 5000 and 0 < int(m.group(2)) < 200        # the re-seeding rescue is handed back
+
+
+def test_map_core_sort_restates_libstdcxx():
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cpu_mapper")
+    p = subprocess.run([exe, "--sort-selftest"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and b"sort selftest OK" in p.stdout, p.stdout[-300:]
