@@ -1117,11 +1117,7 @@ int pack_params(const alfa_dp_params* p, DevParams* dp) {
     if (!p) return alfa::fail(ALFA_EINVAL, "null scoring parameters");
     if (p->m < 1 || p->m > 8) return alfa::fail(ALFA_EINVAL, "m (residue types) must be in 1..8");
     if (p->gapo < 0 || p->gape < 0) return alfa::fail(ALFA_EINVAL, "gap penalties must be passed as non-negative numbers");
-    memset(dp, 0, sizeof(*dp));
-    for (int t = 0; t < p->m; ++t)
-        for (int q = 0; q < p->m; ++q) dp->matrow[t] |= (uint64_t)(uint8_t)p->mat[t * p->m + q] << (8 * q);
-    dp->m = p->m; dp->gapo = p->gapo; dp->gape = p->gape; dp->zdrop = p->zdrop;
-    for (int i = 0; i < p->m * p->m; ++i) dp->maxs = std::max<int>(dp->maxs, p->mat[i]);
+    dev_params_from(*p, *dp);
     return ALFA_OK;
 }
 

@@ -7,6 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
+
+#include "../../include/alfa_hot.h"
 
 namespace {
 
@@ -33,6 +36,15 @@ struct DevParams {
 };
 
 struct ExtOut { int32_t score, qle, tle, gtle, gscore, max_off; };
+
+// the device form of validated scoring parameters (1 <= m <= 8, non-negative penalties)
+inline void dev_params_from(const alfa_dp_params& p, DevParams& dp) {
+    memset(&dp, 0, sizeof(dp));
+    for (int t = 0; t < p.m; ++t)
+        for (int q = 0; q < p.m; ++q) dp.matrow[t] |= (uint64_t)(uint8_t)p.mat[t * p.m + q] << (8 * q);
+    dp.m = p.m; dp.gapo = p.gapo; dp.gape = p.gape; dp.zdrop = p.zdrop;
+    for (int i = 0; i < p.m * p.m; ++i) dp.maxs = dp.maxs > p.mat[i] ? dp.maxs : p.mat[i];
+}
 
 // ---------------------------------------------------------------- wave primitives
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

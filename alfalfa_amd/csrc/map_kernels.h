@@ -1,0 +1,49 @@
+// map_kernels.h -- launcher of the per-read mapping kernel (map_kernels.hip) for seed_kernels.hip's entry point
+// alfa_map_reads_batch: seeds and candidate regions of both strands are on the device already (seed kernels, regions_kernel);
+// one wavefront per read runs the reference's trial loop over them (csrc/map_core.h) with the banded DP inside the kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/alfa_hot.h"
+#include "map_core.h"
+
+namespace alfa {
+
+struct MapKernelArgs {
+    // text
+    const uint8_t* S;               // S[0]
+    int64_t N;
+    const int64_t* startpos;        // device copy of the sequences' start offsets
+    int32_t n_seq;
+    // reads: strand 2r is the forward read of r, 2r + 1 its reverse complement
+    const uint8_t* reads;           // packed read bytes
+    const int64_t* read_off;        // [2n] offset of every strand in `reads`
+    const mapcore::ReadParams* rp;  // [n]
+    int32_t n;
+    // seeds -> regions (regions_kernel's outputs, slotted per strand)
+    const int64_t* base;            // [2n + 1] first match of every strand
+    const alfa_region* reg;         // strand s: reg[base[s] ..]
+    const alfa_match* members;      // strand s: members[2 * base[s] + 8 * s ..]
+    const int32_t* nreg;            // [2n]
+    const int32_t* rstatus;         // [2n] regions_kernel's status
+    // DP
+    const void* dp_params;          // DevParams (ksw_wave.h)
+    uint8_t* scratch;               // n slots of scratch_stride bytes: nt4 query and target of the task in flight
+    int32_t scratch_stride, qcap;   // a slot holds a query of up to qcap bytes at 16 and a target behind it
+    mapcore::Options opt;
+    // results, slotted per read
+    int32_t* status;                // [n] mapcore::Status
+    int32_t* naln;                  // [n]
+    int32_t* nseed;                 // [n]
+    mapcore::AlnOut* alns;          // [n * ALN_CAP]
+    alfa_match* seeds;              // [n * CHAINOUT_CAP]
+};
+
+void launch_map(hipStream_t st, const MapKernelArgs& a);
+// dense copies of the slotted results: read r's alignments to out_alns[aln_off[r] ..], its chain seeds to out_seeds[seed_off[r] ..]
+void launch_map_compact(hipStream_t st, int n, const int32_t* naln, const int32_t* nseed, const int32_t* aln_off, const int32_t* seed_off,
+                        const mapcore::AlnOut* alns, const alfa_match* seeds, mapcore::AlnOut* out_alns, alfa_match* out_seeds);
+
+}  // namespace alfa

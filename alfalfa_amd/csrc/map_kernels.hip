@@ -1,0 +1,197 @@
+// map_kernels.hip -- whole reads on the device (the part round 2 left on the host): after the seed kernels
+// and regions_kernel, one wavefront per read runs the reference's trial loop
+//   unpairedMatch        src/mapper.cpp:1269-1302
+//   processLisIntervals  src/mapper.cpp:1118-1204
+//   extendAlignmentChain src/mapper.cpp:869-1081  (nextChain :721-782, left/rightExtension :784-867)
+// over the read's candidate regions, with every ksw_nw / ksw_extend call it makes executed in place by the same wavefront
+// (wave_task of ksw_wave.h: band-diagonal registers, all 64 lanes on the one task, the reference's moving band followed
+// exactly), so that round k's DP results feed round k + 1's chain selection without leaving the GPU.  The control logic is
+// csrc/map_core.h, compiled here for the device: every lane executes the same statements on the read's state in LDS, which
+// keeps the control flow wave-uniform around the collective DP calls; the loops that are worth it (loading a region's seeds,
+// ranking the anchors, staging the nt4 strings of a DP task) are strided over the lanes.
+// A read the kernel cannot finish exactly as the reference would -- a capacity of map_core.h exceeded, a DP task outside the
+// wave kernel's envelope, regions_kernel's hand-backs, the re-seeding rescue -- comes back with status NEED_CALLER and
+// the caller maps it through the batch entry points as before.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#define MC_FN __device__ __forceinline__
+#include "map_kernels.h"
+#include "ksw_wave.h"
+
+namespace alfa {
+
+namespace {
+
+using mapcore::AlnOut;
+using mapcore::ExtRes;
+using mapcore::Work;
+
+// Utils::ORDVALUE src/utils.h:55-80 for a byte of the read or of the text
+__device__ __forceinline__ uint8_t nt4_of(uint8_t c) {
+    const uint8_t l = c | 0x20;
+    return l == 'a' ? 0 : l == 'c' ? 1 : l == 'g' ? 2 : l == 't' ? 3 : 4;
+}
+
+constexpr int SEQ_OFF = 16;        // wave_task's 8-byte windows may start a few bytes in front of a sequence
+
+struct DevEnv {
+    const MapKernelArgs& A;
+    int ln, r;
+    const uint8_t* Pf;
+    const uint8_t* Pr;
+    uint8_t* scr;
+    const DevParams* prm;
+    const alfa_region* regF; const alfa_region* regR;
+    const alfa_match* memF; const alfa_match* memR;
+    int nF, nR;
+
+    __device__ int lane() const { return ln; }
+    __device__ int lanes() const { return 64; }
+    __device__ void sync() const { __syncthreads(); }
+
+    __device__ bool load_region(Work& W, int k, int& n, bool& fw, int& score) {
+        fw = k < nF;
+        const alfa_region g = fw ? regF[k] : regR[k - nF];
+        const alfa_match* m = (fw ? memF : memR) + g.first;
+        n = g.count; score = g.score;
+        if (n > mapcore::MEMBER_CAP || n < 1) return false;
+        __syncthreads();
+        for (int i = ln; i < n; i += 64) { const alfa_match x = m[i]; W.mref[i] = x.ref; W.mq[i] = x.query; W.ml[i] = x.len; }
+        __syncthreads();
+        return true;
+    }
+    // alfa_host_index_chrom_bounds (sparseSA::getChromBounds src/sparseSA.h:180-190)
+    __device__ void chrom_bounds(int64_t pos, int64_t& cs, int64_t& ce) const {
+        int lo = 0, hi = A.n_seq;                   // first start > pos
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (A.startpos[mid] <= pos) lo = mid + 1; else hi = mid; }
+        const int seq = lo - 1 < 0 ? 0 : lo - 1;
+        cs = A.startpos[seq];
+        ce = (A.n_seq > 1 && seq < A.n_seq - 1) ? A.startpos[seq + 1] - 1 : A.N - 1;
+    }
+    // the task's two strings as nt4 codes into this read's scratch slot; false when they do not fit
+    __device__ bool stage(bool fw, bool left, int qFrom, int qLen, int64_t tFrom, int tLen) {
+        if (qLen < 1 || tLen < 1 || qLen > A.qcap || SEQ_OFF + A.qcap + SEQ_OFF + tLen + 16 > A.scratch_stride) return false;
+        if (left ? (tFrom >= A.N || tFrom - tLen + 1 < 0) : (tFrom < 0 || tFrom + tLen > A.N)) return false;
+        const uint8_t* P = fw ? Pf : Pr;
+        uint8_t* q = scr + SEQ_OFF;
+        uint8_t* t = scr + SEQ_OFF + A.qcap + SEQ_OFF;
+        __syncthreads();
+        if (left) {          // both strings reversed: position j is j + 1 residues to the left of the anchor
+            for (int j = ln; j < qLen; j += 64) q[j] = nt4_of(P[qFrom - j]);
+            for (int j = ln; j < tLen; j += 64) t[j] = nt4_of(A.S[tFrom - j]);
+        } else {
+            for (int j = ln; j < qLen; j += 64) q[j] = nt4_of(P[qFrom + j]);
+            for (int j = ln; j < tLen; j += 64) t[j] = nt4_of(A.S[tFrom + j]);
+        }
+        __threadfence_block();
+        __syncthreads();
+        return true;
+    }
+    __device__ DevTask task(int qLen, int tLen, int w, int h0) const {
+        DevTask T;
+        T.qoff = SEQ_OFF; T.toff = SEQ_OFF + A.qcap + SEQ_OFF; T.zoff = 0; T.cigoff = 0; T.ehoff = 0;
+        T.qlen = qLen; T.tlen = tLen; T.w = w; T.h0 = h0; T.orig = 0; T.cigcap = 0; T.cigcap2 = 0; T.pad = 0;
+        return T;
+    }
+    // ksw_nw(qLen, P[qFrom..], tLen, S[tFrom..], ..., w)   src/ksw.c:544, call site src/mapper.cpp:982
+    __device__ bool nw(bool fw, int qFrom, int qLen, int64_t tFrom, int tLen, int w, int& score) {
+        const int lim = qLen > tLen ? qLen : tLen;
+        if (w > lim) w = lim;                       // the band never binds beyond this: identical loops (ksw_kernels.hip effective_w)
+        if (w < 0 || 2 * w + 1 > 256) return false;
+        if (!stage(fw, false, qFrom, qLen, tFrom, tLen)) return false;
+        const DevTask T = task(qLen, tLen, w, 0);
+        ExtOut eo;
+        int s = 0;
+        if (2 * w + 1 <= 128) wave_task_run<MODE_NW, 2>(T, scr, prm, nullptr, eo, s);
+        else wave_task_run<MODE_NW, 4>(T, scr, prm, nullptr, eo, s);
+        score = s;
+        return true;
+    }
+    // ksw_extend(qLen, query, tLen, target, 5, mat, gapo, gape, w, 100, h0, ...)   src/ksw.c:362, call sites src/mapper.cpp:802,845
+    // left: query[j] = P[qAnchor - 1 - j], target[j] = S[tAnchor - 1 - j]; right: query[j] = P[qAnchor + 1 + j], target[j] = S[tAnchor + 1 + j]
+    __device__ bool extend(bool fw, bool left, int qAnchor, int qLen, int64_t tAnchor, int tLen, int w, int h0, ExtRes& r) {
+        // effective band and rows exactly as the batch entry point derives them (ksw_kernels.hip: effective_w, rows_eff)
+        const int gapo = prm->gapo, gape = prm->gape, maxs = prm->maxs;
+        int max_gap = gape > 0 ? (int)((double)(qLen * maxs - gapo) / gape + 1.) : 0x3fffffff;
+        max_gap = max_gap > 1 ? max_gap : 1;
+        w = w < max_gap ? w : max_gap;
+        const int lim = qLen > tLen ? qLen : tLen;
+        if (w > lim) w = lim;
+        if (w < 0 || 2 * w + 1 > 256) return false;
+        const int64_t rows64 = (int64_t)qLen + w + 1;
+        const int rows = tLen < rows64 ? tLen : (int)rows64;        // ksw_extend leaves its row loop at row qlen + w (ksw.c:393-423)
+        if ((int64_t)(h0 < 0 ? 0 : h0) + (int64_t)qLen * maxs >= (1 << 22)) return false;      // packed row-maximum key (wave_task PACK)
+        if (!stage(fw, left, left ? qAnchor - 1 : qAnchor + 1, qLen, left ? tAnchor - 1 : tAnchor + 1, rows)) return false;
+        const DevTask T = task(qLen, rows, w, h0);
+        ExtOut eo;
+        int s = 0;
+        if (2 * w + 1 <= 64) wave_task_run<MODE_EXTEND, 1, true>(T, scr, prm, nullptr, eo, s);
+        else if (2 * w + 1 <= 128) wave_task_run<MODE_EXTEND, 2, true>(T, scr, prm, nullptr, eo, s);
+        else wave_task_run<MODE_EXTEND, 4, true>(T, scr, prm, nullptr, eo, s);
+        r.score = eo.score; r.qle = eo.qle; r.tle = eo.tle; r.gtle = eo.gtle; r.gscore = eo.gscore; r.max_off = eo.max_off;
+        return true;
+    }
+    __device__ void emit(int k, const AlnOut& o) const {
+        if (ln == 0) A.alns[(int64_t)r * mapcore::ALN_CAP + k] = o;
+    }
+    __device__ void emit_seed(int k, int64_t ref, int32_t q, int32_t len) const {
+        if (ln == 0) { alfa_match m; m.ref = ref; m.query = q; m.len = len; A.seeds[(int64_t)r * mapcore::CHAINOUT_CAP + k] = m; }
+    }
+};
+
+__global__ __launch_bounds__(64) void map_kernel(const MapKernelArgs A) {
+    __shared__ Work W;
+    const int r = blockIdx.x, ln = threadIdx.x;
+    if (r >= A.n) return;
+    const int sf = 2 * r, sr = 2 * r + 1;
+    const int64_t bf = A.base[sf], br = A.base[sr], be = A.base[sr + 1];
+    int status = mapcore::DONE, naln = 0, nseed = 0;
+    if (A.rstatus[sf] | A.rstatus[sr]) status = mapcore::NEED_CALLER;           // regions_kernel handed a strand back
+    else if (be == bf) status = A.opt.rescue ? mapcore::NEED_CALLER : mapcore::DONE;      // no seed on either strand: the seed rescue rounds (src/mapper.cpp:542-555) stay with the caller
+    else {
+        DevEnv env{A, ln, r, A.reads + A.read_off[sf], A.reads + A.read_off[sr], A.scratch + (int64_t)r * A.scratch_stride,
+                   (const DevParams*)A.dp_params, A.reg + bf, A.reg + br, A.members + 2 * bf + 8 * (int64_t)sf,
+                   A.members + 2 * br + 8 * (int64_t)sr, A.nreg[sf], A.nreg[sr]};
+        const int nreg = env.nF + env.nR;
+        if (nreg > mapcore::REGION_CAP2) status = mapcore::NEED_CALLER;
+        else {
+            for (int k = ln; k < nreg; k += 64) W.rscore[k] = k < env.nF ? env.regF[k].score : env.regR[k - env.nF].score;
+            __syncthreads();
+            status = mapcore::map_read(env, W, A.opt, A.rp[r], nreg);
+            naln = W.nAln; nseed = W.nChainOut;
+        }
+    }
+    if (ln == 0) {
+        const bool ok = status == mapcore::DONE;
+        A.status[r] = status;
+        A.naln[r] = ok ? naln : 0;
+        A.nseed[r] = ok ? nseed : 0;
+    }
+}
+
+__global__ void map_compact_kernel(int n, const int32_t* __restrict__ naln, const int32_t* __restrict__ nseed, const int32_t* __restrict__ aln_off,
+                                   const int32_t* __restrict__ seed_off, const AlnOut* __restrict__ alns, const alfa_match* __restrict__ seeds,
+                                   AlnOut* __restrict__ out_alns, alfa_match* __restrict__ out_seeds) {
+    const int r = blockIdx.x;
+    if (r >= n) return;
+    const int na = naln[r], ns = nseed[r];
+    for (int k = threadIdx.x; k < na; k += blockDim.x) out_alns[aln_off[r] + k] = alns[(int64_t)r * mapcore::ALN_CAP + k];
+    for (int k = threadIdx.x; k < ns; k += blockDim.x) out_seeds[seed_off[r] + k] = seeds[(int64_t)r * mapcore::CHAINOUT_CAP + k];
+}
+
+}  // namespace
+
+void launch_map(hipStream_t st, const MapKernelArgs& a) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(map_kernel, dim3(a.n), dim3(64), 0, st, a);
+}
+
+void launch_map_compact(hipStream_t st, int n, const int32_t* naln, const int32_t* nseed, const int32_t* aln_off, const int32_t* seed_off,
+                        const mapcore::AlnOut* alns, const alfa_match* seeds, mapcore::AlnOut* out_alns, alfa_match* out_seeds) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(map_compact_kernel, dim3(n), dim3(64), 0, st, n, naln, nseed, aln_off, seed_off, alns, seeds, out_alns, out_seeds);
+}
+
+}  // namespace alfa

@@ -42,6 +42,10 @@ int main(int argc, char** argv) {
                                      int64_t* off, alfa_region** reg, int64_t* roff, alfa_match** mem, int64_t* boff, int32_t** chn, int32_t* st) {
             return alfa_seed_regions_batch((alfa_index*)ix, type, q, ed, nq, p, m, off, reg, roff, mem, boff, chn, st);
         };
+        ops->map_reads_batch = [](void* ix, const alfa_map_options* o, const alfa_dp_params* dp, const alfa_map_read* r, int n, int32_t* st, int64_t* aoff,
+                                  alfa_map_alignment** al, int64_t* soff, alfa_match** sd) {
+            return alfa_map_reads_batch((alfa_index*)ix, o, dp, r, n, st, aoff, al, soff, sd);
+        };
         ops->ksw_extend_batch = alfa_ksw_extend_batch;
         ops->ksw_nw_batch = alfa_ksw_nw_batch;
         ops->ksw_global_batch = alfa_ksw_global_batch;

@@ -26,6 +26,10 @@ struct HotOps {
     // optional: seeds and the candidate regions built from them in one call; nullptr = the mapper builds them
     int (*seed_regions_batch)(void*, int, const alfa_seed_query*, const int32_t*, int, const alfa_region_params*, alfa_match**, int64_t*,
                               alfa_region**, int64_t*, alfa_match**, int64_t*, int32_t**, int32_t*) = nullptr;
+    // optional (whole reads): seeds, regions and the trial loop with its DP in one call; nullptr = the mapper
+    // runs the trial loop itself through the batch calls below
+    int (*map_reads_batch)(void*, const alfa_map_options*, const alfa_dp_params*, const alfa_map_read*, int, int32_t*, int64_t*,
+                           alfa_map_alignment**, int64_t*, alfa_match**) = nullptr;
     int (*ksw_extend_batch)(const alfa_dp_params*, const alfa_dp_task*, int, alfa_extend_result*) = nullptr;
     int (*ksw_nw_batch)(const alfa_dp_params*, const alfa_dp_task*, int, int32_t*) = nullptr;
     int (*ksw_global_batch)(const alfa_dp_params*, const alfa_dp_task*, int, int32_t*, uint32_t**, int32_t*, int64_t*) = nullptr;
@@ -75,6 +79,9 @@ class HotSched {
     void submit_align(const AlignReq& r) { align_.push_back(r); }
     void wait();              // returns when every request submitted by this fiber has been answered
     const SchedStats& stats() const { return stats_; }
+    const HotOps& ops() const { return ops_; }
+    const alfa_dp_params& dp_params() const { return prm_; }
+    void add_hot_seconds(double s) { stats_.hot_seconds += s; }
     // when set, every DP task issued is appended to <prefix>.hdr (5 x int32: kind 0 nw|1 global|2 extend, qlen, tlen, w, h0)
     // and <prefix>.seq (query bytes then target bytes); used by bench.py to replay the mapper's real task stream
     void set_task_log(const std::string& prefix);

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <memory>
 #include <cstdlib>
 #include <cstring>
@@ -982,6 +983,83 @@ void Mapper::map_unpaired(Read& read) {
     read.init();
     unpaired_match(read);
     postprocess(read, false);
+}
+
+// ---- whole reads through HotOps::map_reads_batch (alfa_map_reads_batch)
+bool Mapper::device_map_usable() const {
+    // both strands are seeded and tried there; the checker path and the region-only path are alternatives to it
+    return opt_.deviceMap && hot_.ops().map_reads_batch && !opt_.noFW && !opt_.noRC && !opt_.coreTrials && !opt_.deviceRegions;
+}
+
+void Mapper::map_batch(Read* const* reads, int n, std::vector<uint8_t>& done) {
+    done.assign((size_t)n, 0);
+    if (n <= 0) return;
+    const int K = (int)idx_.K();
+    alfa_map_options mo;
+    memset(&mo, 0, sizeof(mo));
+    mo.match = opt_.match; mo.mismatch = opt_.mismatch; mo.open_gap = opt_.openGap; mo.extend_gap = opt_.extendGap;
+    mo.global = opt_.global ? 1 : 0; mo.fixed_band = opt_.fixedBandSize; mo.max_trial = opt_.maxTrial; mo.max_trial_best = opt_.maxTrialBest ? 1 : 0;
+    mo.max_aln_count = opt_.maxAlnCount; mo.rescue = opt_.rescue ? 1 : 0;
+    mo.mem_type = opt_.memType; mo.max_seed_candidates = opt_.maxSeedCandidates; mo.max_smem_start = opt_.maxSmemMemStart;
+    mo.max_region_mems = opt_.maxRegionMems; mo.min_mem_reg_length = opt_.minMemRegLength; mo.error_percent = opt_.errorPercent;
+    std::vector<alfa_map_read> rd((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const Read& r = *reads[i];
+        const int Plength = (int)r.sequence.length();
+        const mapcore::ReadParams R = core_read_params(opt_, Plength);
+        // min_len: calculateCandRegions src/mapper.cpp:1225-1231; sparseSkip: calculateSeedsBothStrands :533-536
+        int min_len = opt_.minMemLength;
+        if (!opt_.fixedMinLength && Plength >= 1000) min_len += (20 * ((int)(Plength / 500))) / ((int)100 * opt_.errorPercent);
+        if (opt_.fixedMinLength && Plength / R.editDist > min_len) min_len = Plength / R.editDist;
+        int sparseSkip = K >= 4 ? std::max((min_len - 10) / K, 1) : std::max((min_len - 12) / K, 1);
+        if (opt_.noSparseQ) sparseSkip = 1;
+        alfa_map_read& x = rd[(size_t)i];
+        x.P = r.sequence.data(); x.Prc = r.rcSequence.data(); x.plen = Plength;
+        x.min_len = min_len; x.sparse_q = sparseSkip;
+        x.edit_dist = R.editDist; x.min_score = R.minScore; x.min_coverage = R.minCoverage; x.min_score2 = R.minScore2; x.min_coverage2 = R.minCoverage2;
+    }
+    std::vector<int32_t> st((size_t)n);
+    std::vector<int64_t> aoff((size_t)n + 1), soff((size_t)n + 1);
+    alfa_map_alignment* al = nullptr;
+    alfa_match* sd = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = hot_.ops().map_reads_batch(hot_.ops().index, &mo, &hot_.dp_params(), rd.data(), n, st.data(), aoff.data(), &al, soff.data(), &sd);
+    hot_.add_hot_seconds(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    if (rc) {
+        fprintf(stderr, "ERROR: alfa_map_reads_batch failed (%d): %s\n", rc, hot_.ops().last_error ? hot_.ops().last_error() : "");
+        exit(1);
+    }
+    long nd = 0;
+    for (int i = 0; i < n; ++i) {
+        if (st[(size_t)i] != 0) continue;
+        Read& r = *reads[i];
+        for (int64_t k = aoff[(size_t)i]; k < aoff[(size_t)i + 1]; ++k) {
+            const alfa_map_alignment& o = al[k];
+            Alignment* a = new Alignment();
+            a->refB = o.ref_begin; a->refE = o.ref_end; a->qB = o.q_begin; a->qE = o.q_end; a->alignmentScore = o.score;
+            if (!o.forward) a->flag |= 1u << 4;
+            a->refLength = (int)(o.ref_end - o.ref_begin + 1);
+            static_assert(sizeof(Match) == sizeof(alfa_match), "Match == alfa_match");
+            const Match* s0 = (const Match*)(sd + soff[(size_t)i] + o.chain_first);
+            a->chain.assign(s0, s0 + o.chain_count);
+            r.alignments.push_back(a);
+        }
+        done[(size_t)i] = 1;
+        ++nd;
+    }
+    g_core_done += nd;
+    g_core_fallback += n - nd;
+    hot_.ops().free_fn(al);
+    hot_.ops().free_fn(sd);
+}
+
+void Mapper::map_unpaired_rest(Read& read, bool done) {
+    if (!done) unpaired_match(read);
+    postprocess(read, false);
+}
+
+void Mapper::map_mate_rest(Read& read, bool done) {
+    if (!done) unpaired_match(read);
 }
 
 // ------------------------------------------------------------------------------------------ paired end, mode 1

@@ -114,6 +114,14 @@ class Mapper {
     void map_unpaired(Read& read);
     // map_paired: pairedMatch (modes 1..6) + postprocess of both mates (src/main.cpp:179-195)
     void map_paired(Read& m1, Read& m2);
+    // ---- whole reads on the hot path's side (HotOps::map_reads_batch): usable() says whether this option set can go there;
+    // describe() fills the per-read record (the reference's length-dependent arithmetic stays here, on the host); map_batch()
+    // sends reads[0..n) (init() done) and adopts the results: done[i] = 1 when read i has its alignments (as unpaired_match would
+    // have left them), 0 when it still has to be mapped here
+    bool device_map_usable() const;
+    void map_batch(Read* const* reads, int n, std::vector<uint8_t>& done);
+    void map_unpaired_rest(Read& read, bool done);      // what is left of map_unpaired after map_batch: (unpaired_match,) postprocess
+    void map_mate_rest(Read& read, bool done);          // ... of map_mate
     // paired mode 1 split into its independent parts: map_mate on each mate, pair_mates on the pair, finish_mate on each mate
     bool splittable() const { return popt_.mode == 1; }
     void map_mate(Read& r);

@@ -39,6 +39,7 @@ struct Options {
     int fibers = 2048, gpus = 1, device = 0;     // 2048 fibers per worker: measured best on C3 (4096: 500 k, 2048: 667 k, 1024: 650 k, 512: 589 k reads/s)
     bool stats = false;
     bool gpuIndex = false;      // --gpu-index: build the index arrays on the GPU (index_build.hip)
+    int mapBatch = 16384;       // --map-batch: reads per worker and device call when whole reads are mapped on the device
 };
 
 int seed_type(const std::string& t) {       // parseSeedType src/options.cpp:155-172 (CLI names are shifted)
@@ -117,6 +118,7 @@ bool parse(int argc, char** argv, Options& o) {
         else if (is(nullptr, "device")) o.device = atoi(need(i));
         else if (is(nullptr, "stats")) o.stats = true;
         else if (is(nullptr, "gpu-index")) o.gpuIndex = true;
+        else if (is(nullptr, "map-batch")) o.mapBatch = std::max(64, atoi(need(i)));
         else if (is(nullptr, "device-regions")) o.aln.deviceRegions = true;
         else if (is(nullptr, "core-trials")) o.aln.coreTrials = true;
         else if (is(nullptr, "host-trials")) o.aln.deviceMap = false;
@@ -457,7 +459,10 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     // wave of fibers per worker so that parsing (reader thread), mapping + SAM rendering (worker pool) and writing
     // (writer thread) of successive batches overlap.  Batch boundaries do not influence the output.
     const int64_t bpCount = (int64_t)T * 10000000;
-    const size_t readCap = (size_t)T * (size_t)std::max(256, o.fibers);
+    // with whole reads mapped on the device a worker's slice is one device call: bigger slices (o.mapBatch reads per worker) fill the GPU
+    const bool devmap = o.aln.deviceMap && ops[0].map_reads_batch && !o.aln.noFW && !o.aln.noRC && !o.aln.coreTrials && !o.aln.deviceRegions &&
+                        (o.pair1.empty() || o.paired.mode == 1);
+    const size_t readCap = (size_t)T * (size_t)std::max(256, devmap ? std::max(o.fibers, o.mapBatch) : o.fibers);
 
     struct Batch {
         std::vector<Read> a, b;               // b stays empty for single-end input; objects beyond n are spares of earlier batches
@@ -470,7 +475,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     typedef std::unique_ptr<Batch> BatchP;
     long total = 0, mapped1 = 0, mapped2 = 0, printed1 = 0, printed2 = 0;
     double t_parse = 0, t_map = 0, t_print = 0;
-    std::vector<double> w_build((size_t)T, 0.0), w_run((size_t)T, 0.0), w_render((size_t)T, 0.0);   // per worker, --stats
+    std::vector<double> w_build((size_t)T, 0.0), w_run((size_t)T, 0.0), w_render((size_t)T, 0.0), w_dev((size_t)T, 0.0);   // per worker, --stats
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
     // fill(batch) -> false at end of input; work(batch, t, lo, hi) maps and renders reads [lo,hi) on worker t
@@ -545,7 +550,17 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 const double tb0 = now();
                 for (int i = lo; i < hi; i++) materialize(B.ra[i], B.a[i]);
                 const double tb1 = now();
-                scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.map_unpaired(B.a[lo + i]); });
+                if (mp.device_map_usable()) {
+                    // whole reads on the device first (seeds, regions, trial loop with its DP: alfa_map_reads_batch); the fibers
+                    // then run what is left: CIGAR recovery and MAPQ of every read, the whole mapping of the reads handed back
+                    std::vector<Read*> ptr((size_t)(hi - lo));
+                    for (int i = lo; i < hi; i++) { B.a[i].init(); ptr[(size_t)(i - lo)] = &B.a[i]; }
+                    std::vector<uint8_t> done;
+                    mp.map_batch(ptr.data(), hi - lo, done);
+                    w_dev[t] += now() - tb1;
+                    scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.map_unpaired_rest(B.a[lo + i], done[(size_t)i] != 0); });
+                } else
+                    scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.map_unpaired(B.a[lo + i]); });
                 const double tb2 = now();
                 w_build[t] += tb1 - tb0; w_run[t] += tb2 - tb1;
                 struct Fin { double& acc; double t0; decltype(now)& clk; ~Fin() { acc += clk() - t0; } } fin{w_render[t], tb2, now};
@@ -595,7 +610,19 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 std::string& txt = B.text[t];
                 long* c = &B.cnt[(size_t)t * 4];
                 for (int i = lo; i < hi; i++) { materialize(B.ra[i], B.a[i]); materialize(B.rb[i], B.b[i]); }
-                if (mp.splittable()) {
+                if (mp.splittable() && mp.device_map_usable()) {
+                    // paired mode 1 = unpairedMatch on each mate, then pairing: both mates of every pair go to the device as reads
+                    const int nm = 2 * (hi - lo);
+                    std::vector<Read*> ptr((size_t)nm);
+                    for (int i = 0; i < nm; i++) { Read& r = (i & 1) ? B.b[lo + (i >> 1)] : B.a[lo + (i >> 1)]; r.init(); ptr[(size_t)i] = &r; }
+                    std::vector<uint8_t> done;
+                    const double td0 = now();
+                    mp.map_batch(ptr.data(), nm, done);
+                    w_dev[t] += now() - td0;
+                    scheds[t]->run(nm, o.fibers, [&](int i) { mp.map_mate_rest(*ptr[(size_t)i], done[(size_t)i] != 0); });
+                    scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.pair_mates(B.a[lo + i], B.b[lo + i]); });
+                    scheds[t]->run(nm, o.fibers, [&](int i) { mp.finish_mate(*ptr[(size_t)i]); });
+                } else if (mp.splittable()) {
                     // the mates of a pair are independent until they are paired: twice the fibers, half the chain of batch rounds
                     scheds[t]->run(2 * (hi - lo), o.fibers, [&](int i) { mp.map_mate((i & 1) ? B.b[lo + (i >> 1)] : B.a[lo + (i >> 1)]); });
                     scheds[t]->run(hi - lo, o.fibers, [&](int i) { mp.pair_mates(B.a[lo + i], B.b[lo + i]); });
@@ -644,9 +671,9 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         fprintf(stderr, "#QUEUES GPU_MAX_HW_QUEUES %s\n", getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "unset");
         fprintf(stderr, "#STARTUP index_loaded %.3f device_ready %.3f workers_ready %.3f done %.3f (seconds since start)\n", t_index_ready,
                 t_device_ready, t_pool_ready, since_start());
-        double sb = 0, sr = 0, sn = 0, mr = 0;
-        for (int t = 0; t < T; ++t) { sb += w_build[t]; sr += w_run[t]; sn += w_render[t]; mr = std::max(mr, w_run[t]); }
-        fprintf(stderr, "#WORKERS threads %d build_reads %.3f map %.3f (slowest %.3f) render %.3f (thread-seconds)\n", T, sb, sr, mr, sn);
+        double sb = 0, sr = 0, sn = 0, mr = 0, sd = 0;
+        for (int t = 0; t < T; ++t) { sb += w_build[t]; sr += w_run[t]; sn += w_render[t]; mr = std::max(mr, w_run[t]); sd += w_dev[t]; }
+        fprintf(stderr, "#WORKERS threads %d build_reads %.3f map %.3f (slowest %.3f; of which whole-read device calls %.3f) render %.3f (thread-seconds)\n", T, sb, sr, mr, sd, sn);
         fprintf(stderr, "#STATS rounds %ld seed_calls %ld seed_queries %ld extend %ld/%ld nw %ld/%ld global %ld/%ld align %ld/%ld hot_seconds %.3f\n",
                 (long)s.rounds, (long)s.seed_calls, (long)s.seed_queries, (long)s.ext_calls, (long)s.ext_tasks, (long)s.nw_calls,
                 (long)s.nw_tasks, (long)s.glob_calls, (long)s.glob_tasks, (long)s.align_calls, (long)s.align_tasks, s.hot_seconds);

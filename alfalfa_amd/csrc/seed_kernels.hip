@@ -37,6 +37,8 @@
 #include <vector>
 
 #include "device_ctx.h"
+#include "ksw_wave.h"
+#include "map_kernels.h"
 #include "region_kernels.h"
 
 struct alfa_index {
@@ -46,6 +48,8 @@ struct alfa_index {
     uint8_t nul_sub = 0;     // a byte value that occurs nowhere in S (and is not 0): what a NUL inside a read is packed as
     double kbit_fill = 0;    // fraction of the 10-mers that have a sampled suffix: near 1 the presence bitmap filters nothing
     alfa::DevBuf S, SA, LCP, Midx, Mval, CHILD, KMR, KMR2, KBIT, ISA;
+    alfa::DevBuf STARTPOS;   // start offsets of the concatenated sequences (chromosome bounds for the mapping kernel)
+    int n_seq = 0;
 };
 
 namespace {
@@ -1707,10 +1711,12 @@ int alfa_index_upload(const alfa_index_view* v, int device, alfa_index** out) {
         (rc = upload(ix->Mval, v->LCP_M_val, 4 * (size_t)v->nM)) ||
         (ix->has_child && (rc = upload(ix->CHILD, v->CHILD, 4 * (size_t)v->n))) ||
         (ix->has_kmer && (rc = upload(ix->KMR, v->KMR, 8 * (size_t)TABLE))) ||
-        (ix->has_suflink && v->ISA && (rc = upload(ix->ISA, v->ISA, 4 * (size_t)v->n)))) {
+        (ix->has_suflink && v->ISA && (rc = upload(ix->ISA, v->ISA, 4 * (size_t)v->n))) ||
+        (v->n_seq > 0 && v->startpos && (rc = upload(ix->STARTPOS, v->startpos, 8 * (size_t)v->n_seq)))) {
         alfa_index_free(ix);
         return rc;
     }
+    ix->n_seq = (v->n_seq > 0 && v->startpos) ? v->n_seq : 0;
     {
         // A NUL byte inside a read matches no text character in the reference (it only ever compares P[x] with S[y]), but the
         // kernels' chunked compares would take it for the NUL padding behind the text: reads are packed with their NULs replaced
@@ -1750,7 +1756,7 @@ int alfa_index_upload(const alfa_index_view* v, int device, alfa_index** out) {
 void alfa_index_free(alfa_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    ix->S.release(); ix->SA.release(); ix->LCP.release(); ix->Midx.release(); ix->Mval.release(); ix->CHILD.release(); ix->KMR.release(); ix->KMR2.release(); ix->KBIT.release(); ix->ISA.release();
+    ix->S.release(); ix->SA.release(); ix->LCP.release(); ix->Midx.release(); ix->Mval.release(); ix->CHILD.release(); ix->KMR.release(); ix->KMR2.release(); ix->KBIT.release(); ix->ISA.release(); ix->STARTPOS.release();
     delete ix;
 }
 
@@ -1774,6 +1780,10 @@ struct alfa_seed_plan {
     int64_t out_cap = 0;
     alfa::DevBuf d_reads, d_q, d_tot, d_base, d_work, d_cnt, d_out, d_tmp, d_scr, d_q3;
     alfa::DevBuf d_reg, d_rm, d_chain, d_aux;     // alfa_seed_regions_batch: regions, their members, first chains, per-strand ints
+    // alfa_map_reads_batch: per-read parameters and strand offsets, DP scratch, slotted and dense results, scoring parameters
+    alfa::DevBuf d_mrp, d_moff, d_mscr, d_mint, d_maln, d_mseed, d_maln2, d_mseed2, d_mprm, d_mtmp;
+    alfa::PinBuf h_mint;
+    hipEvent_t mev0 = nullptr, mev1 = nullptr;
     size_t tmp_bytes = 0;
     int mem_type = ALFA_SEED_SMAM;
     size_t work_rec = sizeof(WorkRec);
@@ -2022,11 +2032,10 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
     return ALFA_OK;
 }
 
-int plan_fetch(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_match** matches, int64_t* offsets) {
-    if (!pl->launched) return alfa::fail(ALFA_EINVAL, "fetch before launch");
+// waits for the launch, reads the per-query offsets back and, if the work list or the match array overflowed, grows them and
+// launches again: afterwards the matches of query i are d_out[offsets[i] .. offsets[i+1]) on the device
+int plan_settle(alfa_seed_plan* pl, alfa::Ctx* cx, int64_t* offsets) {
     const int nq = pl->nq;
-    offsets[0] = 0;
-    if (nq == 0) { *matches = (alfa_match*)malloc(sizeof(alfa_match)); return ALFA_OK; }
     hipStream_t st = cx->stream;
     int rc;
     for (int attempt = 0;; ++attempt) {
@@ -2049,6 +2058,17 @@ int plan_fetch(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_match** matches, int64_t*
         }
         if ((rc = plan_launch(pl, cx))) return rc;
     }
+    return ALFA_OK;
+}
+
+int plan_fetch(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_match** matches, int64_t* offsets) {
+    if (!pl->launched) return alfa::fail(ALFA_EINVAL, "fetch before launch");
+    const int nq = pl->nq;
+    offsets[0] = 0;
+    if (nq == 0) { *matches = (alfa_match*)malloc(sizeof(alfa_match)); return ALFA_OK; }
+    hipStream_t st = cx->stream;
+    int rc;
+    if ((rc = plan_settle(pl, cx, offsets))) return rc;
     const int64_t total = offsets[nq];
     alfa_match* hm = (alfa_match*)malloc(sizeof(alfa_match) * (size_t)(total + 1));
     if (!hm) return alfa::fail(ALFA_ENOMEM, "out of host memory for the match array");
@@ -2065,15 +2085,18 @@ void plan_release(alfa_seed_plan* pl) {
     pl->d_reads.release(); pl->d_q.release(); pl->d_tot.release(); pl->d_base.release(); pl->d_work.release(); pl->d_out.release();
     pl->d_tmp.release(); pl->d_scr.release(); pl->d_cnt.release(); pl->d_q3.release();
     pl->d_reg.release(); pl->d_rm.release(); pl->d_chain.release(); pl->d_aux.release();
+    for (alfa::DevBuf* b : {&pl->d_mrp, &pl->d_moff, &pl->d_mscr, &pl->d_mint, &pl->d_maln, &pl->d_mseed, &pl->d_maln2, &pl->d_mseed2, &pl->d_mprm, &pl->d_mtmp}) b->release();
+    pl->h_mint.release();
+    if (pl->mev0) { (void)hipEventDestroy(pl->mev0); (void)hipEventDestroy(pl->mev1); pl->mev0 = pl->mev1 = nullptr; }
     for (alfa::DevBuf* b : {&pl->d_qbase, &pl->d_keys, &pl->d_keys2, &pl->d_vals, &pl->d_vals2, &pl->d_fcnt, &pl->d_fscan, &pl->d_frec, &pl->d_sorttmp}) b->release();
     if (pl->ev0) { (void)hipEventDestroy(pl->ev0); (void)hipEventDestroy(pl->ev1); pl->ev0 = pl->ev1 = nullptr; }
 }
 
-// the calling thread's recycled plans (slot 0: alfa_seed_batch, 1: alfa_seed_regions_batch); buried when the thread ends
+// the calling thread's recycled plans (slot 0: alfa_seed_batch, 1: alfa_seed_regions_batch, 2: alfa_map_reads_batch); buried when the thread ends
 // (device_ctx.h: a live thread releases them)
 alfa_seed_plan* thread_plan(int slot) {
     struct Reuse {
-        alfa_seed_plan* p[2] = {nullptr, nullptr};
+        alfa_seed_plan* p[3] = {nullptr, nullptr, nullptr};
         ~Reuse() {
             for (auto*& x : p)
                 if (x) {
@@ -2218,6 +2241,150 @@ int alfa_seed_regions_batch(alfa_index* ix, int mem_type, const alfa_seed_query*
     free(hr_all); free(hm_all); free(hc_all);
     alfa::g_last_timing.kernel_ms = alfa_seed_plan_kernel_ms(pl);
     alfa::g_last_timing.work_units = pl->total_pref;
+    alfa::g_last_timing.launches = 1;
+    return ALFA_OK;
+}
+
+// whole reads: seeds and regions of both strands, then the trial loop with its DP on the device (map_kernels.hip); see
+// include/alfa_hot.h
+int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_dp_params* dp, const alfa_map_read* reads, int n,
+                         int32_t* status, int64_t* aln_off, alfa_map_alignment** alns, int64_t* seed_off, alfa_match** seeds) {
+    alfa::g_last_timing = alfa::Timing();
+    if (!ix || !o || !dp || !aln_off || !alns || !seed_off || !seeds || n < 0 || (n > 0 && (!reads || !status)))
+        return alfa::fail(ALFA_EINVAL, "null argument");
+    if (dp->m < 1 || dp->m > 8 || dp->gapo < 0 || dp->gape < 0) return alfa::fail(ALFA_EINVAL, "bad scoring parameters");
+    if (n > (1 << 24)) return alfa::fail(ALFA_EINVAL, "more than 2^24 reads in one call: split the batch");
+    alfa::Ctx* cx = alfa::thread_ctx(ix->device);
+    if (!cx) return ALFA_ENODEV;
+    static_assert(sizeof(alfa_map_alignment) == sizeof(alfa::mapcore::AlnOut), "alfa_map_alignment == mapcore::AlnOut");
+    *alns = (alfa_map_alignment*)malloc(sizeof(alfa_map_alignment));
+    *seeds = (alfa_match*)malloc(sizeof(alfa_match));
+    if (!*alns || !*seeds) return alfa::fail(ALFA_ENOMEM, "out of host memory");
+    aln_off[0] = seed_off[0] = 0;
+    if (n == 0) return ALFA_OK;
+    if (ix->n_seq <= 0) return alfa::fail(ALFA_EINVAL, "the index was uploaded without its sequence start offsets");
+    alfa_seed_plan* pl = thread_plan(2);
+    const int nq = 2 * n;
+    int rc;
+    int max_plen = 0, max_edit = 0;
+    std::vector<alfa_seed_query> q((size_t)nq);
+    for (int i = 0; i < n; ++i) {
+        const alfa_map_read& r = reads[i];
+        if (r.plen < 0 || (r.plen > 0 && (!r.P || !r.Prc))) return alfa::fail(ALFA_EINVAL, "bad read");
+        q[2 * i] = alfa_seed_query{r.P, r.plen, r.min_len, o->max_seed_candidates, r.sparse_q, o->max_smem_start};
+        q[2 * i + 1] = alfa_seed_query{r.Prc, r.plen, r.min_len, o->max_seed_candidates, r.sparse_q, o->max_smem_start};
+        max_plen = std::max(max_plen, r.plen);
+        max_edit = std::max(max_edit, r.edit_dist);
+    }
+    if ((rc = plan_fill(pl, cx, ix, o->mem_type, q.data(), nq))) return rc;
+    std::vector<int64_t> h_off((size_t)nq + 1);      // strand offsets in the packed read buffer (plan_fill's descriptors are still in h_tasks)
+    {
+        const SeedQ* hq = cx->h_tasks.as<SeedQ>();
+        for (int i = 0; i < nq; ++i) h_off[i] = hq[i].poff;
+    }
+    if ((rc = plan_launch(pl, cx))) return rc;
+    std::vector<int64_t> moff((size_t)nq + 1);
+    moff[0] = 0;
+    if ((rc = plan_settle(pl, cx, moff.data()))) return rc;
+    const int64_t total = moff[nq];
+    const size_t rm_slots = 2 * (size_t)total + 8 * (size_t)nq;
+    hipStream_t st = cx->stream;
+    // ---- regions of every strand (regions_kernel)
+    if ((rc = pl->d_reg.reserve(sizeof(alfa_region) * (size_t)(total + 1))) || (rc = pl->d_rm.reserve(sizeof(alfa_match) * (rm_slots + 1))) ||
+        (rc = pl->d_chain.reserve(4 * (rm_slots + 1))) || (rc = pl->d_aux.reserve(4 * 5 * (size_t)nq + 64)) || (rc = cx->h_tasks.reserve(4 * 5 * (size_t)nq + 64)))
+        return rc;
+    int32_t* h_aux = cx->h_tasks.as<int32_t>();                 // [qlen | edit | nreg | nrm | status]
+    for (int i = 0; i < nq; ++i) { h_aux[i] = reads[i >> 1].plen; h_aux[nq + i] = reads[i >> 1].edit_dist; }
+    int32_t* d_aux = pl->d_aux.as<int32_t>();
+    ALFA_HIP(hipMemcpyAsync(d_aux, h_aux, 4 * 2 * (size_t)nq, hipMemcpyHostToDevice, st));
+    alfa::RegionParams rp;
+    rp.max_smem_occ = o->max_seed_candidates < 0 ? INT64_MAX : o->max_seed_candidates;
+    rp.max_region_mems = o->max_region_mems < 0 ? INT64_MAX : o->max_region_mems;
+    rp.min_mem_reg_length = o->min_mem_reg_length;
+    rp.error_percent = o->error_percent;
+    alfa::launch_regions(st, pl->d_out.as<alfa_match>(), pl->d_base.as<int64_t>(), d_aux, d_aux + nq, nq, rp, pl->d_reg.as<alfa_region>(),
+                         pl->d_rm.as<alfa_match>(), pl->d_chain.as<int32_t>(), d_aux + 2 * (size_t)nq, d_aux + 3 * (size_t)nq, d_aux + 4 * (size_t)nq);
+    ALFA_HIP(hipGetLastError());
+    // ---- the trial loop, one wavefront per read (map_kernel)
+    using alfa::mapcore::ALN_CAP;
+    using alfa::mapcore::CHAINOUT_CAP;
+    const int qcap = (max_plen + 15) & ~15;
+    const int64_t stride64 = (16 + (int64_t)qcap + 16 + (int64_t)max_plen + max_edit + 64 + 255) & ~(int64_t)255;
+    if (stride64 > (1 << 30)) return alfa::fail(ALFA_EINVAL, "read too long for the mapping kernel's scratch");
+    const size_t nints = (size_t)n + 4 * ((size_t)n + 1);              // status[n] | naln[n+1] | nseed[n+1] | aln_off[n+1] | seed_off[n+1]  (int32)
+    size_t tmp_bytes = 0;
+    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int32_t*)nullptr, (int32_t*)nullptr, n + 1, st));
+    if ((rc = pl->d_mrp.reserve(sizeof(alfa::mapcore::ReadParams) * (size_t)n)) || (rc = pl->d_moff.reserve(8 * ((size_t)nq + 1))) ||
+        (rc = pl->d_mscr.reserve((size_t)stride64 * (size_t)n + 64)) || (rc = pl->d_mint.reserve(4 * (nints + 8))) ||
+        (rc = pl->d_maln.reserve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP)) || (rc = pl->d_mseed.reserve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP)) ||
+        (rc = pl->d_maln2.reserve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP)) || (rc = pl->d_mseed2.reserve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP)) ||
+        (rc = pl->d_mprm.reserve(sizeof(DevParams))) || (rc = pl->d_mtmp.reserve(tmp_bytes + 64)) || (rc = pl->h_mint.reserve(4 * (nints + 8))) ||
+        (rc = cx->h_in2.reserve(sizeof(alfa::mapcore::ReadParams) * (size_t)n + sizeof(DevParams) + 64)))
+        return rc;
+    if (!pl->mev0) { ALFA_HIP(hipEventCreate(&pl->mev0)); ALFA_HIP(hipEventCreate(&pl->mev1)); }
+    {
+        alfa::mapcore::ReadParams* hr = cx->h_in2.as<alfa::mapcore::ReadParams>();
+        for (int i = 0; i < n; ++i) {
+            const alfa_map_read& r = reads[i];
+            hr[i].plen = r.plen; hr[i].editDist = r.edit_dist; hr[i].minScore = r.min_score; hr[i].minCoverage = r.min_coverage;
+            hr[i].minScore2 = r.min_score2; hr[i].minCoverage2 = r.min_coverage2;
+        }
+        DevParams* hp = (DevParams*)(hr + n);
+        dev_params_from(*dp, *hp);
+        ALFA_HIP(hipMemcpyAsync(pl->d_mrp.p, hr, sizeof(alfa::mapcore::ReadParams) * (size_t)n, hipMemcpyHostToDevice, st));
+        ALFA_HIP(hipMemcpyAsync(pl->d_mprm.p, hp, sizeof(DevParams), hipMemcpyHostToDevice, st));
+        ALFA_HIP(hipMemcpyAsync(pl->d_moff.p, h_off.data(), 8 * (size_t)nq, hipMemcpyHostToDevice, st));
+    }
+    int32_t* d_int = pl->d_mint.as<int32_t>();
+    int32_t* d_status = d_int;
+    int32_t* d_naln = d_int + n;                     // n + 1 entries, the last stays 0
+    int32_t* d_nseed = d_naln + (n + 1);
+    int32_t* d_aoff = d_nseed + (n + 1);
+    int32_t* d_soff = d_aoff + (n + 1);
+    ALFA_HIP(hipMemsetAsync(d_int, 0, 4 * (nints + 8), st));
+    alfa::MapKernelArgs A;
+    A.S = ix->S.as<uint8_t>() + PADB; A.N = ix->N; A.startpos = ix->STARTPOS.as<int64_t>(); A.n_seq = ix->n_seq;
+    A.reads = pl->d_reads.as<uint8_t>(); A.read_off = pl->d_moff.as<int64_t>(); A.rp = pl->d_mrp.as<alfa::mapcore::ReadParams>(); A.n = n;
+    A.base = pl->d_base.as<int64_t>(); A.reg = pl->d_reg.as<alfa_region>(); A.members = pl->d_rm.as<alfa_match>();
+    A.nreg = d_aux + 2 * (size_t)nq; A.rstatus = d_aux + 4 * (size_t)nq;
+    A.dp_params = pl->d_mprm.p; A.scratch = pl->d_mscr.as<uint8_t>(); A.scratch_stride = (int32_t)stride64; A.qcap = qcap;
+    A.opt.match = o->match; A.opt.mismatch = o->mismatch; A.opt.openGap = o->open_gap; A.opt.extendGap = o->extend_gap;
+    A.opt.global = o->global; A.opt.fixedBandSize = o->fixed_band; A.opt.maxTrial = o->max_trial; A.opt.maxTrialBest = o->max_trial_best;
+    A.opt.maxAlnCount = o->max_aln_count; A.opt.rescue = o->rescue; A.opt.errorPercent = o->error_percent;
+    A.status = d_status; A.naln = d_naln; A.nseed = d_nseed;
+    A.alns = pl->d_maln.as<alfa::mapcore::AlnOut>(); A.seeds = pl->d_mseed.as<alfa_match>();
+    ALFA_HIP(hipEventRecord(pl->mev0, st));
+    alfa::launch_map(st, A);
+    ALFA_HIP(hipGetLastError());
+    ALFA_HIP(hipEventRecord(pl->mev1, st));
+    size_t tb = tmp_bytes;
+    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_mtmp.p, tb, d_naln, d_aoff, n + 1, st));
+    tb = tmp_bytes;
+    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_mtmp.p, tb, d_nseed, d_soff, n + 1, st));
+    alfa::launch_map_compact(st, n, d_naln, d_nseed, d_aoff, d_soff, pl->d_maln.as<alfa::mapcore::AlnOut>(), pl->d_mseed.as<alfa_match>(),
+                             pl->d_maln2.as<alfa::mapcore::AlnOut>(), pl->d_mseed2.as<alfa_match>());
+    ALFA_HIP(hipGetLastError());
+    int32_t* h_int = pl->h_mint.as<int32_t>();
+    ALFA_HIP(hipMemcpyAsync(h_int, d_int, 4 * nints, hipMemcpyDeviceToHost, st));
+    ALFA_HIP(hipStreamSynchronize(st));
+    const int32_t* h_status = h_int;
+    const int32_t* h_aoff = h_int + n + 2 * ((size_t)n + 1);
+    const int32_t* h_soff = h_aoff + (n + 1);
+    for (int i = 0; i < n; ++i) status[i] = h_status[i];
+    for (int i = 0; i <= n; ++i) { aln_off[i] = h_aoff[i]; seed_off[i] = h_soff[i]; }
+    const int64_t ta = aln_off[n], ts = seed_off[n];
+    alfa_map_alignment* ha = (alfa_map_alignment*)realloc(*alns, sizeof(alfa_map_alignment) * (size_t)(ta + 1));
+    if (ha) *alns = ha;
+    alfa_match* hs = (alfa_match*)realloc(*seeds, sizeof(alfa_match) * (size_t)(ts + 1));
+    if (hs) *seeds = hs;
+    if (!ha || !hs) return alfa::fail(ALFA_ENOMEM, "out of host memory for the alignments");
+    if (ta > 0) ALFA_HIP(hipMemcpyAsync(ha, pl->d_maln2.p, sizeof(alfa_map_alignment) * (size_t)ta, hipMemcpyDeviceToHost, st));
+    if (ts > 0) ALFA_HIP(hipMemcpyAsync(hs, pl->d_mseed2.p, sizeof(alfa_match) * (size_t)ts, hipMemcpyDeviceToHost, st));
+    ALFA_HIP(hipStreamSynchronize(st));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, pl->mev0, pl->mev1) != hipSuccess) { (void)hipGetLastError(); ms = 0; }
+    alfa::g_last_timing.kernel_ms = ms;
+    alfa::g_last_timing.work_units = n;
     alfa::g_last_timing.launches = 1;
     return ALFA_OK;
 }

@@ -144,6 +144,41 @@ int  alfa_seed_regions_batch(alfa_index*, int mem_type, const alfa_seed_query* q
                              alfa_region** regions, int64_t* region_off, alfa_match** members, int64_t* member_off, int32_t** chains,
                              int32_t* status);
 
+/* --- whole reads: seeds -> regions -> the trial loop with its DP, on the device ---------------------- */
+/* replaces, for n independent reads: unpairedMatch (src/mapper.cpp:1269-1302) up to, and not including, its re-seeding
+ * rescue: calculateCandRegions on both strands (:1220-1267: executeSeedType, identifyAndFilter, coveredBases, the sort by
+ * score), processLisIntervals (:1118-1204) with extendAlignmentChain (:869-1081: nextChain, the closed-form gap cases, ksw_nw
+ * per remaining gap, the two ksw_extend calls, duplicate suppression) and the looser second pass (:1283-1289).  Nothing
+ * leaves the GPU between the steps: the DP results of one chain decide the next chain inside the kernel.
+ *   status[i] == 0: read i is done.  Its alignments, in the order the reference appends them to read.alignments, are
+ *                   (*alns)[aln_off[i] .. aln_off[i+1]); alignment a's chain (the seeds constructCIGAR walks, :172-271) is
+ *                   (*seeds)[seed_off[i] + a.chain_first .. + a.chain_count).  No alignments = the reference finds none
+ *                   without re-seeding either (possible only with rescue == 0, or when the read has seeds but no region).
+ *   status[i] == 1: the caller maps read i itself through the entry points above (what the reference does next is the
+ *                   re-seeding rescue, :542-555 or :1290-1300; or a capacity of the kernel was exceeded: more than 192 seeds
+ *                   in a region, 128 regions, 8 alignments or 24 chains per region, a band beyond 256 diagonals; or a strand
+ *                   alfa_seed_regions_batch would hand back).  Results are then empty for that read.
+ * The float arithmetic that depends only on the read length stays on the host and arrives per read (alfa_map_read), so
+ * that the device never rounds differently from the reference.  aln_off, seed_off: n+1 entries, status: n (caller-allocated);
+ * *alns and *seeds are library-allocated (alfa_free).  dp: the parameters the mapper passes to ksw_extend / ksw_nw. */
+typedef struct {
+    int32_t match, mismatch, open_gap, extend_gap;     /* alnOptions values; the two gap penalties NEGATIVE as alnOptions holds them */
+    int32_t global, fixed_band, max_trial, max_trial_best, max_aln_count, rescue;
+    int32_t mem_type, max_seed_candidates, max_smem_start, max_region_mems, min_mem_reg_length, reserved;
+    double error_percent;
+} alfa_map_options;
+typedef struct {
+    const char* P; const char* Prc;     /* the read and its reverse complement as the mapper holds them (lower-case ASCII) */
+    int32_t plen;
+    int32_t min_len, sparse_q;          /* seed parameters: src/mapper.cpp:1226-1231 and :533-536 */
+    int32_t edit_dist;                  /* (int)(errorPercent * plen) + 1                                   :1224 */
+    int32_t min_score, min_coverage;    /* first pass                                                        :1281, :1282 */
+    int32_t min_score2, min_coverage2;  /* second pass (looser thresholds, at most 20 alignments)            :1285-1287 */
+} alfa_map_read;
+typedef struct { int64_t ref_begin, ref_end; int32_t q_begin, q_end, score, forward, chain_first, chain_count; } alfa_map_alignment;
+int  alfa_map_reads_batch(alfa_index*, const alfa_map_options* o, const alfa_dp_params* dp, const alfa_map_read* reads, int n,
+                          int32_t* status, int64_t* aln_off, alfa_map_alignment** alns, int64_t* seed_off, alfa_match** seeds);
+
 /* --- banded DP ---------------------------------------------------------- */
 /* replaces: ksw_extend(...)  src/ksw.h:106 / src/ksw.c:362 */
 int  alfa_ksw_extend_batch(const alfa_dp_params* p, const alfa_dp_task* t, int n, alfa_extend_result* r);
