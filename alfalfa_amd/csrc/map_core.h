@@ -34,13 +34,18 @@ constexpr int TREE_CAP = 128;       // distinct read positions in hasUnique's in
 constexpr int BOUND_CAP = 24;       // chains tried in one region (alnBounds)
 constexpr int ALN_CAP = 8;          // alignments reported per read
 constexpr int CHAINOUT_CAP = 96;    // seeds of all reported chains of a read
+constexpr int OPS_CAP = 160;        // extended CIGAR operations of a read's reported alignments
+constexpr int BAM_CAP = 96;         // BAM CIGAR operations of one ksw_global call
 
 enum Status { DONE = 0, NEED_CALLER = 1 };      // NEED_CALLER: the caller maps this read itself (a capacity was exceeded, the
                                                 // re-seeding rescue is due, a DP task is outside the wave kernel's envelope)
+// An alignment whose extended CIGAR was not made here (it is not among the first `cigarCount` by score, or a capacity was
+// exceeded, or a ksw_global call was degenerate) has opCount = -1: the caller recovers it through ksw_global as before.
 
 struct Options {                    // align_opt (src/options.h), the fields the trial loop reads
     int32_t match, mismatch, openGap, extendGap;     // openGap / extendGap as alnOptions holds them: negative
     int32_t global, fixedBandSize, maxTrial, maxTrialBest, maxAlnCount, rescue;
+    int32_t cigarCount, pad_;       // extended CIGARs for the first cigarCount alignments by score (alignmentCount; 0 = none)
     double errorPercent;
 };
 
@@ -52,7 +57,8 @@ struct ReadParams {                 // derived on the host from the read length 
 
 struct Trial { int64_t refB, refE; int32_t qB, qE; };
 struct ExtRes { int32_t score, qle, tle, gtle, gscore, max_off; };      // = alfa_extend_result
-struct AlnOut { int64_t refB, refE; int32_t qB, qE, score, fw, chainFirst, chainCount; };
+struct AlnOut { int64_t refB, refE; int32_t qB, qE, score, fw, chainFirst, chainCount, opFirst, opCount, editDist, pad_; };
+struct CigOp { int32_t len, code; };            // code: the operation's character ('=', 'X', 'I', 'D', 'S'); len as the reference prints it
 
 struct Work {                       // one read's state (LDS on the device)
     int64_t mref[MEMBER_CAP];                       // the current region's seeds, in the order coveredBases leaves them
@@ -67,7 +73,13 @@ struct Work {                       // one read's state (LDS on the device)
     int32_t treeN[2];
     uint16_t rorder[REGION_CAP2];
     int32_t rscore[REGION_CAP2];
-    int32_t nAln, nChainOut, fail;
+    AlnOut alns[ALN_CAP];                           // the read's alignments, in the order the reference appends them
+    int64_t cref[CHAINOUT_CAP];                     // their chains' seeds
+    int32_t cq[CHAINOUT_CAP], cl[CHAINOUT_CAP];
+    CigOp ops[OPS_CAP];
+    uint32_t bam[BAM_CAP];
+    uint16_t aorder[ALN_CAP];
+    int32_t nAln, nChainOut, nOps, fail;
 };
 
 // ---- std::sort as libstdc++ implements it (bits/stl_algo.h: __sort -> __introsort_loop + __final_insertion_sort, threshold
@@ -321,11 +333,11 @@ MC_FN int try_region(Env& env, Work& W, const Options& O, const ReadParams& R, i
                 if (nAcc >= BOUND_CAP || W.nAln >= ALN_CAP || W.nChainOut + chainLen > CHAINOUT_CAP) { W.fail = 1; return best; }
                 AlnOut o;
                 o.refB = rB; o.refE = rE; o.qB = qB; o.qE = qE; o.score = score; o.fw = fw ? 1 : 0;
-                o.chainFirst = W.nChainOut; o.chainCount = chainLen;
-                env.emit(W.nAln, o);
+                o.chainFirst = W.nChainOut; o.chainCount = chainLen; o.opFirst = 0; o.opCount = -1; o.editDist = 0; o.pad_ = 0;
+                W.alns[W.nAln] = o;
                 for (int c = 0; c < chainLen; ++c) {
                     const int k = chain_at(W, a, nBack, c);
-                    env.emit_seed(W.nChainOut + c, W.mref[k], W.mq[k], W.ml[k]);
+                    W.cref[W.nChainOut + c] = W.mref[k]; W.cq[W.nChainOut + c] = W.mq[k]; W.cl[W.nChainOut + c] = W.ml[k];
                 }
                 W.nChainOut += chainLen;
                 W.nAln += 1;
@@ -365,11 +377,141 @@ MC_FN void run_regions(Env& env, Work& W, const Options& O, const ReadParams& R,
     }
 }
 
+// bandSizeEstimate src/mapper.cpp:44-52
+MC_FN int band_estimate(int fixedBand, int qLen, int refLen, int matchScore, int gapOpen, int gapExtend, int alnScore) {
+    const int d = qLen - refLen > refLen - qLen ? qLen - refLen : refLen - qLen;
+    const int minBand = d + 3;
+    const int scoreBand = ((qLen < refLen ? qLen : refLen) * matchScore - alnScore + gapOpen) / (-1 * gapExtend) + 1;
+    const int maxGapBand = minBand - 3 + ((qLen >> 1) * matchScore + gapOpen) / (-1 * gapExtend) + 1;
+    int band = maxGapBand < scoreBand ? maxGapBand : scoreBand;
+    band = fixedBand < band ? fixedBand : band;
+    band = minBand > band ? minBand : band;
+    return band;
+}
+
+MC_FN bool push_op(Work& W, int32_t len, char code) {
+    if (W.nOps >= OPS_CAP) return false;
+    CigOp o; o.len = len; o.code = (int32_t)code;
+    W.ops[W.nOps++] = o;
+    return true;
+}
+
+// one ksw_global call of constructCIGAR (src/mapper.cpp:200,239,256) and recoverCIGAR4 (:80-117) on its result: the BAM
+// operations expanded to '=' / 'X' runs by comparing read and text; adds mismatches + gap bases to `edit`
+template <class Env>
+MC_FN bool dp_piece(Env& env, Work& W, bool fw, int qFrom, int qLen, int64_t tFrom, int tLen, int band, int& edit) {
+    int first = 0;
+    const int n = env.global_cigar(W, fw, qFrom, qLen, tFrom, tLen, band, first);
+    if (n < 0) return false;
+    int x = 0, y = 0;
+    for (int k = 0; k < n; ++k) {
+        const uint32_t c = W.bam[first + k];
+        const int op = (int)(c & 0xf), len = (int)(c >> 4);
+        if (op == 0) {
+            // maximal runs of equal / unequal residues, in order (nt4 codes are compared: n equals n)
+            int run = 0;
+            bool runEq = true;
+            for (int at = 0; at < len; at += 64) {
+                const int m = len - at < 64 ? len - at : 64;
+                uint64_t eq = env.equal_mask(fw, qFrom + x + at, tFrom + y + at, m);
+                int i = 0;
+                while (i < m) {
+                    const bool e = (eq >> i) & 1;
+                    // length of the stretch of bits equal to e from i on (inside this chunk)
+                    const uint64_t diff = (e ? ~eq : eq) >> i;
+                    int st = diff ? __builtin_ctzll(diff) : 64;
+                    if (st > m - i) st = m - i;
+                    if (run > 0 && e != runEq) { if (!push_op(W, run, runEq ? '=' : 'X')) return false; run = 0; }
+                    if (!e) edit += st;
+                    runEq = e; run += st; i += st;
+                }
+            }
+            if (run > 0 && !push_op(W, run, runEq ? '=' : 'X')) return false;
+            x += len; y += len;
+        } else {
+            if (!push_op(W, len, "MIDSH"[op])) return false;
+            if (op == 1) { x += len; edit += len; }
+            else if (op == 2) { y += len; edit += len; }
+        }
+    }
+    return true;
+}
+
+// constructCIGAR src/mapper.cpp:172-271 for one alignment: soft clips, the chain's seeds as '=' runs, the closed-form gap
+// cases (:207-243, mirroring the scoring cases), one ksw_global per remaining gap and for the head and the tail
+template <class Env>
+MC_FN bool cigar_one(Env& env, Work& W, const Options& O, const ReadParams& R, AlnOut& a) {
+    const bool fw = a.fw != 0;
+    int edit = 0;
+    a.opFirst = W.nOps;
+    if (a.qB && !push_op(W, a.qB, 'S')) return false;
+    const int c0 = a.chainFirst, cn = a.chainCount;
+    if (W.cq[c0] > a.qB) {
+        const int qLen = W.cq[c0] - a.qB, refLen = (int)(W.cref[c0] - a.refB);
+        const int band = band_estimate(O.fixedBandSize, qLen, refLen, O.match, O.openGap, O.extendGap, a.score);
+        if (!dp_piece(env, W, fw, a.qB, qLen, a.refB, refLen, band, edit)) return false;
+    }
+    if (!push_op(W, W.cl[c0], '=')) return false;
+    for (int i = 1; i < cn; ++i) {
+        const int p = c0 + i - 1, c = c0 + i;
+        int qDist = W.cq[c] - (W.cq[p] + W.cl[p] - 1);
+        int refDist = (int)(W.cref[c] - (W.cref[p] + W.cl[p] - 1));
+        if (qDist < 0 || refDist < 0) {
+            if (qDist >= refDist) qDist -= refDist; else refDist -= qDist;
+        }
+        bool ok = true;
+        if (qDist <= 0) { ok = push_op(W, refDist, 'D') && push_op(W, W.cl[c] - 1 + qDist, '='); edit += refDist; }
+        else if (refDist <= 0) { ok = push_op(W, qDist, 'I') && push_op(W, W.cl[c] - 1 + refDist, '='); edit += qDist; }
+        else if (qDist == 1) { ok = push_op(W, refDist - 1, 'D') && push_op(W, W.cl[c], '='); edit += refDist - 1; }
+        else if (refDist == 1) { ok = push_op(W, qDist - 1, 'I') && push_op(W, W.cl[c], '='); edit += qDist - 1; }
+        else if (refDist == 2 && qDist == 2) { ok = push_op(W, 1, 'X') && push_op(W, W.cl[c], '='); edit += 1; }
+        else {
+            const int qLen = W.cq[c] - 1 - (W.cq[p] + W.cl[p]) + 1;
+            const int refLen = (int)(W.cref[c] - 1 - (W.cref[p] + W.cl[p]) + 1);
+            const int band = band_estimate(O.fixedBandSize, qLen, refLen, O.match, O.openGap, O.extendGap, a.score);
+            ok = dp_piece(env, W, fw, W.cq[p] + W.cl[p], qLen, W.cref[p] + W.cl[p], refLen, band, edit) && push_op(W, W.cl[c], '=');
+        }
+        if (!ok) return false;
+    }
+    const int l = c0 + cn - 1;
+    if (W.cq[l] + W.cl[l] - 1 < a.qE) {
+        const int qLen = a.qE - (W.cq[l] + W.cl[l]) + 1, refLen = (int)(a.refE - (W.cref[l] + W.cl[l]) + 1);
+        const int band = band_estimate(O.fixedBandSize, qLen, refLen, O.match, O.openGap, O.extendGap, a.score);
+        if (!dp_piece(env, W, fw, W.cq[l] + W.cl[l], qLen, W.cref[l] + W.cl[l], refLen, band, edit)) return false;
+    }
+    if (R.plen - 1 - a.qE && !push_op(W, R.plen - 1 - a.qE, 'S')) return false;
+    a.opCount = W.nOps - a.opFirst;
+    a.editDist = edit;
+    return true;
+}
+
+// read_t::postprocess src/mapper.cpp:322-379, the part in front of the MAPQ: the alignments ordered by score (std::sort with
+// compAlignments :295 -- at most ALN_CAP = 8 elements, where libstdc++ runs a plain insertion sort: stable), extended CIGARs
+// for the first O.cigarCount of them.  An alignment whose CIGAR cannot be made here keeps opCount = -1.
+template <class Env>
+MC_FN void build_cigars(Env& env, Work& W, const Options& O, const ReadParams& R) {
+    W.nOps = 0;
+    const int n = W.nAln;
+    for (int k = 0; k < n; ++k) W.aorder[k] = (uint16_t)k;
+    for (int i = 1; i < n; ++i) {                    // insertion sort by score, descending, stable
+        const uint16_t v = W.aorder[i];
+        int j = i;
+        while (j > 0 && W.alns[W.aorder[j - 1]].score < W.alns[v].score) { W.aorder[j] = W.aorder[j - 1]; --j; }
+        W.aorder[j] = v;
+    }
+    const int want = n < O.cigarCount ? n : O.cigarCount;
+    for (int j = 0; j < want; ++j) {
+        AlnOut& a = W.alns[W.aorder[j]];
+        const int mark = W.nOps;
+        if (!cigar_one(env, W, O, R, a)) { W.nOps = mark; a.opFirst = 0; a.opCount = -1; a.editDist = 0; }
+    }
+}
+
 // unpairedMatch src/mapper.cpp:1269-1302 from the candidate regions on (W.rscore[k] = score of region k, k in the order
 // calculateCandRegions creates them: forward strand first); returns DONE or NEED_CALLER
 template <class Env>
 MC_FN int map_read(Env& env, Work& W, const Options& O, const ReadParams& R, int nRegions) {
-    W.nAln = 0; W.nChainOut = 0; W.fail = 0;
+    W.nAln = 0; W.nChainOut = 0; W.nOps = 0; W.fail = 0;
     if (nRegions > REGION_CAP2) return NEED_CALLER;
     for (int k = 0; k < nRegions; ++k) W.rorder[k] = (uint16_t)k;
     const int32_t* sc = W.rscore;
@@ -382,6 +524,7 @@ MC_FN int map_read(Env& env, Work& W, const Options& O, const ReadParams& R, int
         if (W.fail) return NEED_CALLER;
         if (W.nAln == 0) return NEED_CALLER;                 // the re-seeding rescue (:1290-1300) stays with the caller
     }
+    if (O.cigarCount > 0) build_cigars(env, W, O, R);
     return DONE;
 }
 

@@ -32,18 +32,24 @@ struct MapKernelArgs {
     const void* dp_params;          // DevParams (ksw_wave.h)
     uint8_t* scratch;               // n slots of scratch_stride bytes: nt4 query and target of the task in flight
     int32_t scratch_stride, qcap;   // a slot holds a query of up to qcap bytes at 16 and a target behind it
+    uint8_t* zscratch;              // n slots of zstride bytes: direction bytes of the ksw_global call in flight
+    int64_t zstride;
     mapcore::Options opt;
     // results, slotted per read
     int32_t* status;                // [n] mapcore::Status
     int32_t* naln;                  // [n]
     int32_t* nseed;                 // [n]
+    int32_t* nops;                  // [n]
     mapcore::AlnOut* alns;          // [n * ALN_CAP]
     alfa_match* seeds;              // [n * CHAINOUT_CAP]
+    mapcore::CigOp* ops;            // [n * OPS_CAP]
 };
 
 void launch_map(hipStream_t st, const MapKernelArgs& a);
-// dense copies of the slotted results: read r's alignments to out_alns[aln_off[r] ..], its chain seeds to out_seeds[seed_off[r] ..]
-void launch_map_compact(hipStream_t st, int n, const int32_t* naln, const int32_t* nseed, const int32_t* aln_off, const int32_t* seed_off,
-                        const mapcore::AlnOut* alns, const alfa_match* seeds, mapcore::AlnOut* out_alns, alfa_match* out_seeds);
+// dense copies of the slotted results: read r's alignments to out_alns[aln_off[r] ..], its chain seeds to out_seeds[seed_off[r] ..],
+// its CIGAR operations to out_ops[op_off[r] ..]
+void launch_map_compact(hipStream_t st, int n, const int32_t* naln, const int32_t* nseed, const int32_t* nops, const int32_t* aln_off,
+                        const int32_t* seed_off, const int32_t* op_off, const mapcore::AlnOut* alns, const alfa_match* seeds,
+                        const mapcore::CigOp* ops, mapcore::AlnOut* out_alns, alfa_match* out_seeds, mapcore::CigOp* out_ops);
 
 }  // namespace alfa

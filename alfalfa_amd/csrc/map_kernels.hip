@@ -133,11 +133,56 @@ struct DevEnv {
         r.score = eo.score; r.qle = eo.qle; r.tle = eo.tle; r.gtle = eo.gtle; r.gscore = eo.gscore; r.max_off = eo.max_off;
         return true;
     }
-    __device__ void emit(int k, const AlnOut& o) const {
-        if (ln == 0) A.alns[(int64_t)r * mapcore::ALN_CAP + k] = o;
+    // ksw_global(qLen, P[qFrom..], tLen, S[tFrom..], ..., band)   src/ksw.c:468, call sites src/mapper.cpp:200,239,256: the wave-wide
+    // fill writes one direction byte per cell to this read's slot of A.zscratch, then the walk of ksw.c:524-538 (every lane
+    // the same steps) leaves the BAM operations in forward order at W.bam[first .. first + n).  -1: not done here.
+    __device__ int global_cigar(Work& W, bool fw, int qFrom, int qLen, int64_t tFrom, int tLen, int w, int& first) {
+        if (qLen < 1 || tLen < 1) return -1;                 // degenerate calls (the reference's loops do not run): the caller's path
+        const int lim = qLen > tLen ? qLen : tLen;
+        if (w > lim) w = lim;
+        if (w < 0 || 2 * w + 1 > 256 || tLen > qLen + w) return -1;      // (tlen > qlen + w: the reference indexes outside its matrix)
+        const int C4 = 2 * w + 1 > 128;
+        const int rowb = C4 ? 256 : 128;
+        if ((int64_t)tLen * rowb > A.zstride) return -1;
+        if (!stage(fw, false, qFrom, qLen, tFrom, tLen)) return -1;
+        uint8_t* z = A.zscratch + (int64_t)r * A.zstride;
+        const DevTask T = task(qLen, tLen, w, 0);
+        ExtOut eo;
+        int s = 0;
+        if (!C4) wave_task_run<MODE_GLOBAL, 2>(T, scr, prm, z, eo, s);
+        else wave_task_run<MODE_GLOBAL, 4>(T, scr, prm, z, eo, s);
+        __threadfence_block();
+        __syncthreads();
+        int pos = mapcore::BAM_CAP, n = 0;
+        uint32_t cur_op = 0xffffffffu, cur_len = 0;
+        bool over = false;
+        auto push = [&](uint32_t op, uint32_t len) {
+            if (op == cur_op) { cur_len += len; return; }
+            if (cur_op != 0xffffffffu) { if (pos > 0) W.bam[--pos] = cur_len << 4 | cur_op; else over = true; ++n; }
+            cur_op = op; cur_len = len;
+        };
+        int i = tLen - 1, k = (i + w + 1 < qLen ? i + w + 1 : qLen) - 1;
+        int which = 0;
+        while (i >= 0 && k >= 0) {
+            const uint32_t zv = z[(int64_t)i * rowb + (k - i + w)];
+            which = (zv >> (which << 1)) & 3;
+            if (which == 0) { push(0, 1); --i; --k; }
+            else if (which == 1) { push(2, 1); --i; }
+            else { push(1, 1); --k; }
+        }
+        if (i >= 0) push(2, (uint32_t)(i + 1));
+        if (k >= 0) push(1, (uint32_t)(k + 1));
+        if (cur_op != 0xffffffffu) { if (pos > 0) W.bam[--pos] = cur_len << 4 | cur_op; else over = true; ++n; }
+        if (over) return -1;
+        first = pos;
+        return n;
     }
-    __device__ void emit_seed(int k, int64_t ref, int32_t q, int32_t len) const {
-        if (ln == 0) { alfa_match m; m.ref = ref; m.query = q; m.len = len; A.seeds[(int64_t)r * mapcore::CHAINOUT_CAP + k] = m; }
+    // bit i: nt4(P[qpos + i]) == nt4(S[tpos + i]), i < n <= 64
+    __device__ uint64_t equal_mask(bool fw, int qpos, int64_t tpos, int n) const {
+        const uint8_t* P = fw ? Pf : Pr;
+        bool e = false;
+        if (ln < n) e = nt4_of(P[qpos + ln]) == nt4_of(A.S[tpos + ln]);
+        return __ballot(e);
     }
 };
 
@@ -147,7 +192,7 @@ __global__ __launch_bounds__(64) void map_kernel(const MapKernelArgs A) {
     if (r >= A.n) return;
     const int sf = 2 * r, sr = 2 * r + 1;
     const int64_t bf = A.base[sf], br = A.base[sr], be = A.base[sr + 1];
-    int status = mapcore::DONE, naln = 0, nseed = 0;
+    int status = mapcore::DONE, naln = 0, nseed = 0, nops = 0;
     if (A.rstatus[sf] | A.rstatus[sr]) status = mapcore::NEED_CALLER;           // regions_kernel handed a strand back
     else if (be == bf) status = A.opt.rescue ? mapcore::NEED_CALLER : mapcore::DONE;      // no seed on either strand: the seed rescue rounds (src/mapper.cpp:542-555) stay with the caller
     else {
@@ -160,25 +205,36 @@ __global__ __launch_bounds__(64) void map_kernel(const MapKernelArgs A) {
             for (int k = ln; k < nreg; k += 64) W.rscore[k] = k < env.nF ? env.regF[k].score : env.regR[k - env.nF].score;
             __syncthreads();
             status = mapcore::map_read(env, W, A.opt, A.rp[r], nreg);
-            naln = W.nAln; nseed = W.nChainOut;
+            if (status == mapcore::DONE) {
+                naln = W.nAln; nseed = W.nChainOut; nops = W.nOps;
+                __syncthreads();
+                for (int k = ln; k < naln; k += 64) A.alns[(int64_t)r * mapcore::ALN_CAP + k] = W.alns[k];
+                for (int k = ln; k < nseed; k += 64) {
+                    alfa_match m; m.ref = W.cref[k]; m.query = W.cq[k]; m.len = W.cl[k];
+                    A.seeds[(int64_t)r * mapcore::CHAINOUT_CAP + k] = m;
+                }
+                for (int k = ln; k < nops; k += 64) A.ops[(int64_t)r * mapcore::OPS_CAP + k] = W.ops[k];
+            }
         }
     }
     if (ln == 0) {
-        const bool ok = status == mapcore::DONE;
         A.status[r] = status;
-        A.naln[r] = ok ? naln : 0;
-        A.nseed[r] = ok ? nseed : 0;
+        A.naln[r] = naln;
+        A.nseed[r] = nseed;
+        A.nops[r] = nops;
     }
 }
 
-__global__ void map_compact_kernel(int n, const int32_t* __restrict__ naln, const int32_t* __restrict__ nseed, const int32_t* __restrict__ aln_off,
-                                   const int32_t* __restrict__ seed_off, const AlnOut* __restrict__ alns, const alfa_match* __restrict__ seeds,
-                                   AlnOut* __restrict__ out_alns, alfa_match* __restrict__ out_seeds) {
+__global__ void map_compact_kernel(int n, const int32_t* __restrict__ naln, const int32_t* __restrict__ nseed, const int32_t* __restrict__ nops,
+                                   const int32_t* __restrict__ aln_off, const int32_t* __restrict__ seed_off, const int32_t* __restrict__ op_off,
+                                   const AlnOut* __restrict__ alns, const alfa_match* __restrict__ seeds, const mapcore::CigOp* __restrict__ ops,
+                                   AlnOut* __restrict__ out_alns, alfa_match* __restrict__ out_seeds, mapcore::CigOp* __restrict__ out_ops) {
     const int r = blockIdx.x;
     if (r >= n) return;
-    const int na = naln[r], ns = nseed[r];
+    const int na = naln[r], ns = nseed[r], no = nops[r];
     for (int k = threadIdx.x; k < na; k += blockDim.x) out_alns[aln_off[r] + k] = alns[(int64_t)r * mapcore::ALN_CAP + k];
     for (int k = threadIdx.x; k < ns; k += blockDim.x) out_seeds[seed_off[r] + k] = seeds[(int64_t)r * mapcore::CHAINOUT_CAP + k];
+    for (int k = threadIdx.x; k < no; k += blockDim.x) out_ops[op_off[r] + k] = ops[(int64_t)r * mapcore::OPS_CAP + k];
 }
 
 }  // namespace
@@ -188,10 +244,12 @@ void launch_map(hipStream_t st, const MapKernelArgs& a) {
     hipLaunchKernelGGL(map_kernel, dim3(a.n), dim3(64), 0, st, a);
 }
 
-void launch_map_compact(hipStream_t st, int n, const int32_t* naln, const int32_t* nseed, const int32_t* aln_off, const int32_t* seed_off,
-                        const mapcore::AlnOut* alns, const alfa_match* seeds, mapcore::AlnOut* out_alns, alfa_match* out_seeds) {
+void launch_map_compact(hipStream_t st, int n, const int32_t* naln, const int32_t* nseed, const int32_t* nops, const int32_t* aln_off,
+                        const int32_t* seed_off, const int32_t* op_off, const mapcore::AlnOut* alns, const alfa_match* seeds,
+                        const mapcore::CigOp* ops, mapcore::AlnOut* out_alns, alfa_match* out_seeds, mapcore::CigOp* out_ops) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(map_compact_kernel, dim3(n), dim3(64), 0, st, n, naln, nseed, aln_off, seed_off, alns, seeds, out_alns, out_seeds);
+    hipLaunchKernelGGL(map_compact_kernel, dim3(n), dim3(64), 0, st, n, naln, nseed, nops, aln_off, seed_off, op_off, alns, seeds, ops, out_alns,
+                       out_seeds, out_ops);
 }
 
 }  // namespace alfa

@@ -43,8 +43,8 @@ int main(int argc, char** argv) {
             return alfa_seed_regions_batch((alfa_index*)ix, type, q, ed, nq, p, m, off, reg, roff, mem, boff, chn, st);
         };
         ops->map_reads_batch = [](void* ix, const alfa_map_options* o, const alfa_dp_params* dp, const alfa_map_read* r, int n, int32_t* st, int64_t* aoff,
-                                  alfa_map_alignment** al, int64_t* soff, alfa_match** sd) {
-            return alfa_map_reads_batch((alfa_index*)ix, o, dp, r, n, st, aoff, al, soff, sd);
+                                  alfa_map_alignment** al, int64_t* soff, alfa_match** sd, int64_t* ooff, alfa_map_cigar_op** op) {
+            return alfa_map_reads_batch((alfa_index*)ix, o, dp, r, n, st, aoff, al, soff, sd, ooff, op);
         };
         ops->ksw_extend_batch = alfa_ksw_extend_batch;
         ops->ksw_nw_batch = alfa_ksw_nw_batch;

@@ -29,7 +29,7 @@ struct HotOps {
     // optional (whole reads): seeds, regions and the trial loop with its DP in one call; nullptr = the mapper
     // runs the trial loop itself through the batch calls below
     int (*map_reads_batch)(void*, const alfa_map_options*, const alfa_dp_params*, const alfa_map_read*, int, int32_t*, int64_t*,
-                           alfa_map_alignment**, int64_t*, alfa_match**) = nullptr;
+                           alfa_map_alignment**, int64_t*, alfa_match**, int64_t*, alfa_map_cigar_op**) = nullptr;
     int (*ksw_extend_batch)(const alfa_dp_params*, const alfa_dp_task*, int, alfa_extend_result*) = nullptr;
     int (*ksw_nw_batch)(const alfa_dp_params*, const alfa_dp_task*, int, int32_t*) = nullptr;
     int (*ksw_global_batch)(const alfa_dp_params*, const alfa_dp_task*, int, int32_t*, uint32_t**, int32_t*, int64_t*) = nullptr;

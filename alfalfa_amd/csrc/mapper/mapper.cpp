@@ -167,18 +167,36 @@ void Read::release() {
     pairedAlignmentCount = 0;
 }
 
+// read_t::init src/mapper.h:155-166: reverse complement, reversed qualities, nt4 codes of both strands -- one pass with tables
+// (the byte-wise switch version was a third of a worker's time once whole reads are mapped on the device)
+namespace {
+struct Nt4Table {
+    uint8_t t[256];
+    Nt4Table() { for (int i = 0; i < 256; ++i) t[i] = nt4((unsigned char)i); }
+};
+const Nt4Table NT4;
+}  // namespace
+
 void Read::init() {
-    rcSequence = sequence;
-    std::reverse(rcSequence.begin(), rcSequence.end());
-    for (auto& c : rcSequence) c = RC.t[(unsigned char)c];
-    rQual = qual;
-    std::reverse(rQual.begin(), rQual.end());
-    readP.resize(sequence.size());
-    rcReadP.resize(sequence.size());
-    for (size_t i = 0; i < sequence.size(); ++i) {
-        readP[i] = nt4((unsigned char)sequence[i]);
-        rcReadP[i] = nt4((unsigned char)rcSequence[i]);
+    const size_t n = sequence.size(), nq = qual.size();
+    rcSequence.resize(n);
+    rQual.resize(nq);
+    readP.resize(n);
+    rcReadP.resize(n);
+    const unsigned char* s = (const unsigned char*)sequence.data();
+    char* rc = &rcSequence[0];
+    uint8_t* p = readP.data();
+    uint8_t* rp = rcReadP.data();
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char c = s[i];
+        const char r = RC.t[c];
+        p[i] = NT4.t[c];
+        rc[n - 1 - i] = r;
+        rp[n - 1 - i] = NT4.t[(unsigned char)r];
     }
+    const char* q = qual.data();
+    char* rq = &rQual[0];
+    for (size_t i = 0; i < nq; ++i) rq[nq - 1 - i] = q[i];
 }
 
 // read_t::emptyAlingment src/mapper.h:170-179
@@ -715,7 +733,6 @@ void Mapper::process_lis(Read& read, const std::vector<Lis>& lis, int editDist, 
 namespace {
 struct CoreEnv {
     const RefIndex& idx; HotSched& hot; const Read& read; const std::vector<Mapper_Lis_view>* lis;
-    std::vector<mapcore::AlnOut> alns; std::vector<Match> seeds;
     int lane() const { return 0; }
     int lanes() const { return 1; }
     void sync() const {}
@@ -751,18 +768,41 @@ struct CoreEnv {
         r.score = e.score; r.qle = e.qle; r.tle = e.tle; r.gtle = e.gtle; r.gscore = e.gscore; r.max_off = e.max_off;
         return true;
     }
-    void emit(int k, const mapcore::AlnOut& o) { if ((int)alns.size() <= k) alns.resize((size_t)k + 1); alns[(size_t)k] = o; }
-    void emit_seed(int k, int64_t ref, int32_t q, int32_t len) { if ((int)seeds.size() <= k) seeds.resize((size_t)k + 1); seeds[(size_t)k] = Match{ref, q, len}; }
+    // ksw_global through the scheduler; the BAM operations to W.bam[0 .. n)
+    int global_cigar(mapcore::Work& W, bool fw, int qFrom, int qLen, int64_t tFrom, int tLen, int band, int& first) {
+        const uint8_t* rp = fw ? read.readP.data() : read.rcReadP.data();
+        const char* S = idx.S();
+        std::vector<uint8_t> t((size_t)std::max(tLen, 0));
+        for (int k = 0; k < tLen; ++k) t[k] = nt4((unsigned char)S[tFrom + k]);
+        int32_t score = 0;
+        std::vector<uint32_t> cg;
+        hot.submit_global(GlobalReq{alfa_dp_task{rp + qFrom, t.data(), qLen, tLen, band, 0}, &score, &cg});
+        hot.wait();
+        first = 0;
+        if (cg.size() > (size_t)mapcore::BAM_CAP) return -1;
+        for (size_t k = 0; k < cg.size(); ++k) W.bam[k] = cg[k];
+        return (int)cg.size();
+    }
+    uint64_t equal_mask(bool fw, int qpos, int64_t tpos, int n) const {
+        const uint8_t* rp = fw ? read.readP.data() : read.rcReadP.data();
+        const char* S = idx.S();
+        uint64_t m = 0;
+        for (int i = 0; i < n; ++i) m |= (uint64_t)(rp[qpos + i] == nt4((unsigned char)S[tpos + i])) << i;
+        return m;
+    }
 };
 }  // namespace
 
 std::atomic<long> g_core_done{0}, g_core_fallback{0};
+std::atomic<long> g_map_us[4];      // whole-read device calls, microseconds over all workers: describe, the call, adopt; [3] counts the
+                                    // alignments whose CIGAR came with them
 
 mapcore::Options core_options(const AlignOpt& o) {
     mapcore::Options O;
     O.match = o.match; O.mismatch = o.mismatch; O.openGap = o.openGap; O.extendGap = o.extendGap;
     O.global = o.global ? 1 : 0; O.fixedBandSize = o.fixedBandSize; O.maxTrial = o.maxTrial; O.maxTrialBest = o.maxTrialBest ? 1 : 0;
     O.maxAlnCount = o.maxAlnCount; O.rescue = o.rescue ? 1 : 0; O.errorPercent = o.errorPercent;
+    O.cigarCount = o.fullDP ? 0 : o.alignmentCount; O.pad_ = 0;       // --full-dp recomputes whole alignments: no chain CIGARs
     return O;
 }
 
@@ -783,7 +823,7 @@ bool Mapper::core_trials(Read& read, const std::vector<Lis>& lis) {
     std::vector<Mapper_Lis_view> view;
     view.reserve(lis.size());
     for (const Lis& l : lis) view.push_back(Mapper_Lis_view{&l.matches, l.fw, l.score});
-    CoreEnv env{idx_, hot_, read, &view, {}, {}};
+    CoreEnv env{idx_, hot_, read, &view};
     std::unique_ptr<mapcore::Work> W(new mapcore::Work());
     if (lis.size() > (size_t)mapcore::REGION_CAP2) return false;
     for (size_t k = 0; k < lis.size(); ++k) W->rscore[k] = lis[k].score;
@@ -791,12 +831,14 @@ bool Mapper::core_trials(Read& read, const std::vector<Lis>& lis) {
     const mapcore::ReadParams R = core_read_params(opt_, (int)read.sequence.length());
     if (mapcore::map_read(env, *W, O, R, (int)lis.size()) != mapcore::DONE) return false;
     for (int k = 0; k < W->nAln; ++k) {
-        const mapcore::AlnOut& o = env.alns[(size_t)k];
+        const mapcore::AlnOut& o = W->alns[k];
         Alignment* a = new Alignment();
         a->refB = o.refB; a->refE = o.refE; a->qB = o.qB; a->qE = o.qE; a->alignmentScore = o.score;
         if (!o.fw) a->flag |= 1u << 4;
         a->refLength = (int)(o.refE - o.refB + 1);
-        a->chain.assign(env.seeds.begin() + o.chainFirst, env.seeds.begin() + o.chainFirst + o.chainCount);
+        a->chain.resize((size_t)o.chainCount);
+        for (int c = 0; c < o.chainCount; ++c) a->chain[(size_t)c] = Match{W->cref[o.chainFirst + c], W->cq[o.chainFirst + c], W->cl[o.chainFirst + c]};
+        if (o.opCount >= 0) { a->ops.assign(W->ops + o.opFirst, W->ops + o.opFirst + o.opCount); a->haveOps = true; a->opsEdit = o.editDist; }
         read.alignments.push_back(a);
     }
     return true;
@@ -858,18 +900,23 @@ void Mapper::set_local_pos(Alignment& a) {
 // read_t::postprocess src/mapper.cpp:322-379 with constructCIGAR :172-271 and fullDP :303-320.
 // All ksw_global calls of a read (one per chain gap + head + tail of every reported alignment) are independent:
 // they are submitted together and the strings are assembled afterwards in the reference's order.
-void Mapper::postprocess(Read& read, bool paired) {
-    if (read.alignments.empty()) return;
+bool Mapper::postprocess(Read& read, bool paired, bool mayWait) {
+    if (read.alignments.empty()) return true;
     auto& al = read.alignments;
     if (!paired) std::sort(al.begin(), al.end(), cmp_aln);
     else std::sort(al.begin(), al.end(), cmp_aln_paired);
     int maxDP = std::min((int)al.size(), opt_.alignmentCount);
     if (opt_.fullDP) maxDP = std::min((int)al.size(), std::max(4, opt_.alignmentCount));
+    if (!mayWait) {
+        // not on a fiber: only when every alignment that gets a CIGAR brought its operations along
+        for (int j = 0; j < maxDP; j++)
+            if (opt_.fullDP || !al[j]->haveOps) return false;
+    }
     const char* S = idx_.S();
     const int Plen = (int)read.sequence.length();
     struct Piece { int kind; std::string lit; int dp; int editAdd; };   // kind 0: literal text (+edit), 1: DP result #dp
     struct DpJob { std::vector<uint32_t> cigar; int32_t score; const uint8_t* q; const uint8_t* t; };
-    struct Plan { std::vector<uint8_t> target; std::vector<Piece> pieces; bool full = false; int fullJob = -1; };
+    struct Plan { std::vector<uint8_t> target; std::vector<Piece> pieces; bool full = false; int fullJob = -1; bool fromOps = false; };
     std::vector<Plan> plans((size_t)maxDP);
     std::deque<DpJob> jobs;               // references stay valid across push_back (the scheduler holds pointers into the jobs)
     std::vector<DpJob*> jobv;
@@ -886,6 +933,7 @@ void Mapper::postprocess(Read& read, bool paired) {
         set_local_pos(a);
         const uint8_t* readP = a.rc() ? read.rcReadP.data() : read.readP.data();
         Plan& pl = plans[j];
+        if (a.haveOps && !opt_.fullDP) { pl.fromOps = true; continue; }       // constructCIGAR's result came with the alignment
         int qLen = a.qE - a.qB + 1;
         int refLen = (int)(a.refE - a.refB + 1);
         pl.target.resize((size_t)std::max(refLen, 0));
@@ -943,7 +991,14 @@ void Mapper::postprocess(Read& read, bool paired) {
     for (int j = 0; j < maxDP; j++) {
         Alignment& a = *al[j];
         Plan& pl = plans[j];
-        if (!pl.full) {
+        if (pl.fromOps) {
+            g_map_us[3]++;
+            Txt sNM;
+            for (const mapcore::CigOp& o : a.ops) sNM << o.len << (char)o.code;
+            a.editDist = a.opsEdit;
+            a.NMtag = sNM.str();
+            a.cigar = cigar3_from4(a.NMtag);
+        } else if (!pl.full) {
             Txt sNM;
             a.editDist = 0;
             for (const Piece& p : pl.pieces) {
@@ -977,6 +1032,7 @@ void Mapper::postprocess(Read& read, bool paired) {
         if (al[j]->alignmentScore + al[j]->mate.alignmentScore == maxScore) al[j]->mapq = mapq;
         else al[j]->flag |= 1u << 8;
     }
+    return true;
 }
 
 void Mapper::map_unpaired(Read& read) {
@@ -1003,6 +1059,7 @@ void Mapper::map_batch(Read* const* reads, int n, std::vector<uint8_t>& done) {
     mo.mem_type = opt_.memType; mo.max_seed_candidates = opt_.maxSeedCandidates; mo.max_smem_start = opt_.maxSmemMemStart;
     mo.max_region_mems = opt_.maxRegionMems; mo.min_mem_reg_length = opt_.minMemRegLength; mo.error_percent = opt_.errorPercent;
     std::vector<alfa_map_read> rd((size_t)n);
+    const auto tm0 = std::chrono::steady_clock::now();
     for (int i = 0; i < n; ++i) {
         const Read& r = *reads[i];
         const int Plength = (int)r.sequence.length();
@@ -1019,12 +1076,17 @@ void Mapper::map_batch(Read* const* reads, int n, std::vector<uint8_t>& done) {
         x.edit_dist = R.editDist; x.min_score = R.minScore; x.min_coverage = R.minCoverage; x.min_score2 = R.minScore2; x.min_coverage2 = R.minCoverage2;
     }
     std::vector<int32_t> st((size_t)n);
-    std::vector<int64_t> aoff((size_t)n + 1), soff((size_t)n + 1);
+    std::vector<int64_t> aoff((size_t)n + 1), soff((size_t)n + 1), ooff((size_t)n + 1);
     alfa_map_alignment* al = nullptr;
     alfa_match* sd = nullptr;
+    alfa_map_cigar_op* op = nullptr;
+    mo.cigar_alignments = opt_.fullDP ? 0 : opt_.alignmentCount;
     const auto t0 = std::chrono::steady_clock::now();
-    const int rc = hot_.ops().map_reads_batch(hot_.ops().index, &mo, &hot_.dp_params(), rd.data(), n, st.data(), aoff.data(), &al, soff.data(), &sd);
-    hot_.add_hot_seconds(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    const int rc = hot_.ops().map_reads_batch(hot_.ops().index, &mo, &hot_.dp_params(), rd.data(), n, st.data(), aoff.data(), &al, soff.data(), &sd, ooff.data(), &op);
+    const auto t1 = std::chrono::steady_clock::now();
+    hot_.add_hot_seconds(std::chrono::duration<double>(t1 - t0).count());
+    g_map_us[0] += (long)std::chrono::duration<double, std::micro>(t0 - tm0).count();
+    g_map_us[1] += (long)std::chrono::duration<double, std::micro>(t1 - t0).count();
     if (rc) {
         fprintf(stderr, "ERROR: alfa_map_reads_batch failed (%d): %s\n", rc, hot_.ops().last_error ? hot_.ops().last_error() : "");
         exit(1);
@@ -1042,6 +1104,13 @@ void Mapper::map_batch(Read* const* reads, int n, std::vector<uint8_t>& done) {
             static_assert(sizeof(Match) == sizeof(alfa_match), "Match == alfa_match");
             const Match* s0 = (const Match*)(sd + soff[(size_t)i] + o.chain_first);
             a->chain.assign(s0, s0 + o.chain_count);
+            if (o.op_count >= 0) {
+                static_assert(sizeof(mapcore::CigOp) == sizeof(alfa_map_cigar_op), "CigOp == alfa_map_cigar_op");
+                const mapcore::CigOp* p0 = (const mapcore::CigOp*)(op + ooff[(size_t)i] + o.op_first);
+                a->ops.assign(p0, p0 + o.op_count);
+                a->haveOps = true;
+                a->opsEdit = o.edit_dist;
+            }
             r.alignments.push_back(a);
         }
         done[(size_t)i] = 1;
@@ -1051,12 +1120,16 @@ void Mapper::map_batch(Read* const* reads, int n, std::vector<uint8_t>& done) {
     g_core_fallback += n - nd;
     hot_.ops().free_fn(al);
     hot_.ops().free_fn(sd);
+    hot_.ops().free_fn(op);
+    g_map_us[2] += (long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
 }
 
 void Mapper::map_unpaired_rest(Read& read, bool done) {
     if (!done) unpaired_match(read);
     postprocess(read, false);
 }
+
+bool Mapper::finish_unpaired_direct(Read& read) { return postprocess(read, false, false); }
 
 void Mapper::map_mate_rest(Read& read, bool done) {
     if (!done) unpaired_match(read);

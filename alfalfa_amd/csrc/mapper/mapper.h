@@ -74,6 +74,10 @@ struct Alignment {                // alignment_t src/mapper.h:80-124
     int refLength = 0;
     MateInfo mate;
     std::vector<Match> chain;
+    // extended CIGAR made with the alignment (whole reads on the device / --core-trials): constructCIGAR's output as operations
+    std::vector<mapcore::CigOp> ops;
+    bool haveOps = false;
+    int opsEdit = 0;
     bool paired() const { return flag & 1u; }
     bool concordant() const { return paired() && mate.concordant; }
     bool rc() const { return (flag >> 4) & 1u; }
@@ -121,6 +125,7 @@ class Mapper {
     bool device_map_usable() const;
     void map_batch(Read* const* reads, int n, std::vector<uint8_t>& done);
     void map_unpaired_rest(Read& read, bool done);      // what is left of map_unpaired after map_batch: (unpaired_match,) postprocess
+    bool finish_unpaired_direct(Read& read);            // ... for a read whose CIGARs came with its alignments: no fiber needed; false = needs one
     void map_mate_rest(Read& read, bool done);          // ... of map_mate
     // paired mode 1 split into its independent parts: map_mate on each mate, pair_mates on the pair, finish_mate on each mate
     bool splittable() const { return popt_.mode == 1; }
@@ -146,7 +151,8 @@ class Mapper {
                      int64_t chrStart, int64_t chrEnd, Read& read, bool fw, const Lis* first = nullptr);
     void left_ext(const std::string& P, int& tmpQB, int64_t& tmpRB, int64_t chrStart, int& curScore, int bandSize, int editDist);
     void right_ext(const std::string& P, int& tmpQE, int64_t& tmpRE, int64_t chrEnd, int& curScore, int bandSize, int editDist);
-    void postprocess(Read& read, bool paired);
+    // mayWait = false: returns false, with nothing submitted, when a ksw_global call would be needed (the caller is not on a fiber)
+    bool postprocess(Read& read, bool paired, bool mayWait = true);
     void set_local_pos(Alignment& a);
     void paired_match1(Read& m1, Read& m2);
     void pair_mates1(Read& m1, Read& m2);
@@ -183,6 +189,7 @@ std::string sam_header(const RefIndex& idx, int argc, char** argv);
 // is done here, on the host)
 mapcore::Options core_options(const AlignOpt& o);
 mapcore::ReadParams core_read_params(const AlignOpt& o, int Plength);
+extern std::atomic<long> g_map_us[4];
 extern std::atomic<long> g_core_done, g_core_fallback;     // --core-trials / device mapping: reads done there, reads handed back
 
 }  // namespace alfa

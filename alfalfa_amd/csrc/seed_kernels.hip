@@ -33,6 +33,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -1781,7 +1783,7 @@ struct alfa_seed_plan {
     alfa::DevBuf d_reads, d_q, d_tot, d_base, d_work, d_cnt, d_out, d_tmp, d_scr, d_q3;
     alfa::DevBuf d_reg, d_rm, d_chain, d_aux;     // alfa_seed_regions_batch: regions, their members, first chains, per-strand ints
     // alfa_map_reads_batch: per-read parameters and strand offsets, DP scratch, slotted and dense results, scoring parameters
-    alfa::DevBuf d_mrp, d_moff, d_mscr, d_mint, d_maln, d_mseed, d_maln2, d_mseed2, d_mprm, d_mtmp;
+    alfa::DevBuf d_mrp, d_moff, d_mscr, d_mint, d_maln, d_mseed, d_maln2, d_mseed2, d_mprm, d_mtmp, d_mz, d_mops, d_mops2;
     alfa::PinBuf h_mint;
     hipEvent_t mev0 = nullptr, mev1 = nullptr;
     size_t tmp_bytes = 0;
@@ -2085,7 +2087,7 @@ void plan_release(alfa_seed_plan* pl) {
     pl->d_reads.release(); pl->d_q.release(); pl->d_tot.release(); pl->d_base.release(); pl->d_work.release(); pl->d_out.release();
     pl->d_tmp.release(); pl->d_scr.release(); pl->d_cnt.release(); pl->d_q3.release();
     pl->d_reg.release(); pl->d_rm.release(); pl->d_chain.release(); pl->d_aux.release();
-    for (alfa::DevBuf* b : {&pl->d_mrp, &pl->d_moff, &pl->d_mscr, &pl->d_mint, &pl->d_maln, &pl->d_mseed, &pl->d_maln2, &pl->d_mseed2, &pl->d_mprm, &pl->d_mtmp}) b->release();
+    for (alfa::DevBuf* b : {&pl->d_mrp, &pl->d_moff, &pl->d_mscr, &pl->d_mint, &pl->d_maln, &pl->d_mseed, &pl->d_maln2, &pl->d_mseed2, &pl->d_mprm, &pl->d_mtmp, &pl->d_mz, &pl->d_mops, &pl->d_mops2}) b->release();
     pl->h_mint.release();
     if (pl->mev0) { (void)hipEventDestroy(pl->mev0); (void)hipEventDestroy(pl->mev1); pl->mev0 = pl->mev1 = nullptr; }
     for (alfa::DevBuf* b : {&pl->d_qbase, &pl->d_keys, &pl->d_keys2, &pl->d_vals, &pl->d_vals2, &pl->d_fcnt, &pl->d_fscan, &pl->d_frec, &pl->d_sorttmp}) b->release();
@@ -2248,24 +2250,30 @@ int alfa_seed_regions_batch(alfa_index* ix, int mem_type, const alfa_seed_query*
 // whole reads: seeds and regions of both strands, then the trial loop with its DP on the device (map_kernels.hip); see
 // include/alfa_hot.h
 int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_dp_params* dp, const alfa_map_read* reads, int n,
-                         int32_t* status, int64_t* aln_off, alfa_map_alignment** alns, int64_t* seed_off, alfa_match** seeds) {
+                         int32_t* status, int64_t* aln_off, alfa_map_alignment** alns, int64_t* seed_off, alfa_match** seeds,
+                         int64_t* op_off, alfa_map_cigar_op** ops) {
     alfa::g_last_timing = alfa::Timing();
-    if (!ix || !o || !dp || !aln_off || !alns || !seed_off || !seeds || n < 0 || (n > 0 && (!reads || !status)))
+    if (!ix || !o || !dp || !aln_off || !alns || !seed_off || !seeds || !op_off || !ops || n < 0 || (n > 0 && (!reads || !status)))
         return alfa::fail(ALFA_EINVAL, "null argument");
     if (dp->m < 1 || dp->m > 8 || dp->gapo < 0 || dp->gape < 0) return alfa::fail(ALFA_EINVAL, "bad scoring parameters");
     if (n > (1 << 24)) return alfa::fail(ALFA_EINVAL, "more than 2^24 reads in one call: split the batch");
     alfa::Ctx* cx = alfa::thread_ctx(ix->device);
     if (!cx) return ALFA_ENODEV;
     static_assert(sizeof(alfa_map_alignment) == sizeof(alfa::mapcore::AlnOut), "alfa_map_alignment == mapcore::AlnOut");
+    static_assert(sizeof(alfa_map_cigar_op) == sizeof(alfa::mapcore::CigOp), "alfa_map_cigar_op == mapcore::CigOp");
     *alns = (alfa_map_alignment*)malloc(sizeof(alfa_map_alignment));
     *seeds = (alfa_match*)malloc(sizeof(alfa_match));
-    if (!*alns || !*seeds) return alfa::fail(ALFA_ENOMEM, "out of host memory");
-    aln_off[0] = seed_off[0] = 0;
+    *ops = (alfa_map_cigar_op*)malloc(sizeof(alfa_map_cigar_op));
+    if (!*alns || !*seeds || !*ops) return alfa::fail(ALFA_ENOMEM, "out of host memory");
+    aln_off[0] = seed_off[0] = op_off[0] = 0;
     if (n == 0) return ALFA_OK;
     if (ix->n_seq <= 0) return alfa::fail(ALFA_EINVAL, "the index was uploaded without its sequence start offsets");
     alfa_seed_plan* pl = thread_plan(2);
     const int nq = 2 * n;
     int rc;
+    static const bool call_log = getenv("ALFA_CALL_LOG") != nullptr;      // diagnostics: where the call's time goes
+    const auto tc0 = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     int max_plen = 0, max_edit = 0;
     std::vector<alfa_seed_query> q((size_t)nq);
     for (int i = 0; i < n; ++i) {
@@ -2282,10 +2290,12 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
         const SeedQ* hq = cx->h_tasks.as<SeedQ>();
         for (int i = 0; i < nq; ++i) h_off[i] = hq[i].poff;
     }
+    const double ms_fill = since(tc0);
     if ((rc = plan_launch(pl, cx))) return rc;
     std::vector<int64_t> moff((size_t)nq + 1);
     moff[0] = 0;
     if ((rc = plan_settle(pl, cx, moff.data()))) return rc;
+    const double ms_seeds = since(tc0) - ms_fill;
     const int64_t total = moff[nq];
     const size_t rm_slots = 2 * (size_t)total + 8 * (size_t)nq;
     hipStream_t st = cx->stream;
@@ -2308,10 +2318,16 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     // ---- the trial loop, one wavefront per read (map_kernel)
     using alfa::mapcore::ALN_CAP;
     using alfa::mapcore::CHAINOUT_CAP;
+    using alfa::mapcore::OPS_CAP;
     const int qcap = (max_plen + 15) & ~15;
     const int64_t stride64 = (16 + (int64_t)qcap + 16 + (int64_t)max_plen + max_edit + 64 + 255) & ~(int64_t)255;
     if (stride64 > (1 << 30)) return alfa::fail(ALFA_EINVAL, "read too long for the mapping kernel's scratch");
-    const size_t nints = (size_t)n + 4 * ((size_t)n + 1);              // status[n] | naln[n+1] | nseed[n+1] | aln_off[n+1] | seed_off[n+1]  (int32)
+    const size_t nints = (size_t)n + 6 * ((size_t)n + 1);              // status[n] | naln | nseed | nops | aln_off | seed_off | op_off, n+1 each (int32)
+    // direction bytes of the ksw_global call in flight, per read: the whole read at 256 bytes per row when that is affordable,
+    // else what 256 MiB per call give (at least 16 KiB: 128 rows of a band of up to 128 diagonals); a longer piece's CIGAR
+    // is left to the caller (op_count = -1)
+    const int64_t zworst = 256 * ((int64_t)max_plen + max_edit + 8);
+    const int64_t zstride = o->cigar_alignments > 0 ? std::min(zworst, std::max<int64_t>(16 << 10, (((int64_t)256 << 20) / n) & ~(int64_t)255)) : 0;
     size_t tmp_bytes = 0;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int32_t*)nullptr, (int32_t*)nullptr, n + 1, st));
     if ((rc = pl->d_mrp.reserve(sizeof(alfa::mapcore::ReadParams) * (size_t)n)) || (rc = pl->d_moff.reserve(8 * ((size_t)nq + 1))) ||
@@ -2319,6 +2335,8 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
         (rc = pl->d_maln.reserve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP)) || (rc = pl->d_mseed.reserve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP)) ||
         (rc = pl->d_maln2.reserve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP)) || (rc = pl->d_mseed2.reserve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP)) ||
         (rc = pl->d_mprm.reserve(sizeof(DevParams))) || (rc = pl->d_mtmp.reserve(tmp_bytes + 64)) || (rc = pl->h_mint.reserve(4 * (nints + 8))) ||
+        (rc = pl->d_mz.reserve((size_t)zstride * (size_t)n + 64)) || (rc = pl->d_mops.reserve(sizeof(alfa::mapcore::CigOp) * (size_t)n * OPS_CAP)) ||
+        (rc = pl->d_mops2.reserve(sizeof(alfa::mapcore::CigOp) * (size_t)n * OPS_CAP)) ||
         (rc = cx->h_in2.reserve(sizeof(alfa::mapcore::ReadParams) * (size_t)n + sizeof(DevParams) + 64)))
         return rc;
     if (!pl->mev0) { ALFA_HIP(hipEventCreate(&pl->mev0)); ALFA_HIP(hipEventCreate(&pl->mev1)); }
@@ -2339,8 +2357,10 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     int32_t* d_status = d_int;
     int32_t* d_naln = d_int + n;                     // n + 1 entries, the last stays 0
     int32_t* d_nseed = d_naln + (n + 1);
-    int32_t* d_aoff = d_nseed + (n + 1);
+    int32_t* d_nops = d_nseed + (n + 1);
+    int32_t* d_aoff = d_nops + (n + 1);
     int32_t* d_soff = d_aoff + (n + 1);
+    int32_t* d_ooff = d_soff + (n + 1);
     ALFA_HIP(hipMemsetAsync(d_int, 0, 4 * (nints + 8), st));
     alfa::MapKernelArgs A;
     A.S = ix->S.as<uint8_t>() + PADB; A.N = ix->N; A.startpos = ix->STARTPOS.as<int64_t>(); A.n_seq = ix->n_seq;
@@ -2348,11 +2368,13 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     A.base = pl->d_base.as<int64_t>(); A.reg = pl->d_reg.as<alfa_region>(); A.members = pl->d_rm.as<alfa_match>();
     A.nreg = d_aux + 2 * (size_t)nq; A.rstatus = d_aux + 4 * (size_t)nq;
     A.dp_params = pl->d_mprm.p; A.scratch = pl->d_mscr.as<uint8_t>(); A.scratch_stride = (int32_t)stride64; A.qcap = qcap;
+    A.zscratch = pl->d_mz.as<uint8_t>(); A.zstride = zstride;
+    A.opt.cigarCount = o->cigar_alignments > 0 ? o->cigar_alignments : 0; A.opt.pad_ = 0;
     A.opt.match = o->match; A.opt.mismatch = o->mismatch; A.opt.openGap = o->open_gap; A.opt.extendGap = o->extend_gap;
     A.opt.global = o->global; A.opt.fixedBandSize = o->fixed_band; A.opt.maxTrial = o->max_trial; A.opt.maxTrialBest = o->max_trial_best;
     A.opt.maxAlnCount = o->max_aln_count; A.opt.rescue = o->rescue; A.opt.errorPercent = o->error_percent;
-    A.status = d_status; A.naln = d_naln; A.nseed = d_nseed;
-    A.alns = pl->d_maln.as<alfa::mapcore::AlnOut>(); A.seeds = pl->d_mseed.as<alfa_match>();
+    A.status = d_status; A.naln = d_naln; A.nseed = d_nseed; A.nops = d_nops;
+    A.alns = pl->d_maln.as<alfa::mapcore::AlnOut>(); A.seeds = pl->d_mseed.as<alfa_match>(); A.ops = pl->d_mops.as<alfa::mapcore::CigOp>();
     ALFA_HIP(hipEventRecord(pl->mev0, st));
     alfa::launch_map(st, A);
     ALFA_HIP(hipGetLastError());
@@ -2361,18 +2383,28 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_mtmp.p, tb, d_naln, d_aoff, n + 1, st));
     tb = tmp_bytes;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_mtmp.p, tb, d_nseed, d_soff, n + 1, st));
-    alfa::launch_map_compact(st, n, d_naln, d_nseed, d_aoff, d_soff, pl->d_maln.as<alfa::mapcore::AlnOut>(), pl->d_mseed.as<alfa_match>(),
-                             pl->d_maln2.as<alfa::mapcore::AlnOut>(), pl->d_mseed2.as<alfa_match>());
+    tb = tmp_bytes;
+    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_mtmp.p, tb, d_nops, d_ooff, n + 1, st));
+    alfa::launch_map_compact(st, n, d_naln, d_nseed, d_nops, d_aoff, d_soff, d_ooff, pl->d_maln.as<alfa::mapcore::AlnOut>(), pl->d_mseed.as<alfa_match>(),
+                             pl->d_mops.as<alfa::mapcore::CigOp>(), pl->d_maln2.as<alfa::mapcore::AlnOut>(), pl->d_mseed2.as<alfa_match>(),
+                             pl->d_mops2.as<alfa::mapcore::CigOp>());
     ALFA_HIP(hipGetLastError());
     int32_t* h_int = pl->h_mint.as<int32_t>();
     ALFA_HIP(hipMemcpyAsync(h_int, d_int, 4 * nints, hipMemcpyDeviceToHost, st));
+    const double ms_enq = since(tc0) - ms_fill - ms_seeds;
     ALFA_HIP(hipStreamSynchronize(st));
+    const double ms_map = since(tc0) - ms_fill - ms_seeds - ms_enq;
     const int32_t* h_status = h_int;
-    const int32_t* h_aoff = h_int + n + 2 * ((size_t)n + 1);
+    const int32_t* h_aoff = h_int + n + 3 * ((size_t)n + 1);
     const int32_t* h_soff = h_aoff + (n + 1);
+    const int32_t* h_ooff = h_soff + (n + 1);
     for (int i = 0; i < n; ++i) status[i] = h_status[i];
-    for (int i = 0; i <= n; ++i) { aln_off[i] = h_aoff[i]; seed_off[i] = h_soff[i]; }
-    const int64_t ta = aln_off[n], ts = seed_off[n];
+    for (int i = 0; i <= n; ++i) { aln_off[i] = h_aoff[i]; seed_off[i] = h_soff[i]; op_off[i] = h_ooff[i]; }
+    const int64_t ta = aln_off[n], ts = seed_off[n], to = op_off[n];
+    alfa_map_cigar_op* ho = (alfa_map_cigar_op*)realloc(*ops, sizeof(alfa_map_cigar_op) * (size_t)(to + 1));
+    if (ho) *ops = ho;
+    else return alfa::fail(ALFA_ENOMEM, "out of host memory for the CIGAR operations");
+    if (to > 0) ALFA_HIP(hipMemcpyAsync(ho, pl->d_mops2.p, sizeof(alfa_map_cigar_op) * (size_t)to, hipMemcpyDeviceToHost, st));
     alfa_map_alignment* ha = (alfa_map_alignment*)realloc(*alns, sizeof(alfa_map_alignment) * (size_t)(ta + 1));
     if (ha) *alns = ha;
     alfa_match* hs = (alfa_match*)realloc(*seeds, sizeof(alfa_match) * (size_t)(ts + 1));
@@ -2386,6 +2418,9 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     alfa::g_last_timing.kernel_ms = ms;
     alfa::g_last_timing.work_units = n;
     alfa::g_last_timing.launches = 1;
+    if (call_log)
+        fprintf(stderr, "#MAPCALL reads %d matches %lld alns %lld fill_ms %.3f seeds_ms %.3f enqueue_ms %.3f regions_map_wait_ms %.3f total_ms %.3f map_kernel_ms %.3f seed_kernel_ms %.3f\n",
+                n, (long long)total, (long long)ta, ms_fill, ms_seeds, ms_enq, ms_map, since(tc0), ms, alfa_seed_plan_kernel_ms(pl));
     return ALFA_OK;
 }
 

@@ -574,3 +574,77 @@ def ksw_global_noalloc(params, d_tasks_ptr, n, max_tlen, d_seq_ptr, d_score_ptr,
     rc = L.alfa_ksw_global_noalloc(C.byref(params), d_tasks_ptr, int(n), int(max_tlen), d_seq_ptr, d_score_ptr, d_cigar_ptr, d_ncig_ptr,
                                    int(cig_stride), int(device), stream)
     check(rc)
+
+
+# ---- whole reads (alfa_map_reads_batch)
+class MapOptions(C.Structure):
+    _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("open_gap", C.c_int32), ("extend_gap", C.c_int32),
+                ("global_", C.c_int32), ("fixed_band", C.c_int32), ("max_trial", C.c_int32), ("max_trial_best", C.c_int32),
+                ("max_aln_count", C.c_int32), ("rescue", C.c_int32),
+                ("mem_type", C.c_int32), ("max_seed_candidates", C.c_int32), ("max_smem_start", C.c_int32), ("max_region_mems", C.c_int32),
+                ("min_mem_reg_length", C.c_int32), ("cigar_alignments", C.c_int32), ("error_percent", C.c_double)]
+
+
+class MapRead(C.Structure):
+    _fields_ = [("P", C.c_char_p), ("Prc", C.c_char_p), ("plen", C.c_int32), ("min_len", C.c_int32), ("sparse_q", C.c_int32),
+                ("edit_dist", C.c_int32), ("min_score", C.c_int32), ("min_coverage", C.c_int32), ("min_score2", C.c_int32),
+                ("min_coverage2", C.c_int32)]
+
+
+MAP_ALN_DTYPE = np.dtype([("ref_begin", "<i8"), ("ref_end", "<i8"), ("q_begin", "<i4"), ("q_end", "<i4"), ("score", "<i4"),
+                          ("forward", "<i4"), ("chain_first", "<i4"), ("chain_count", "<i4"), ("op_first", "<i4"), ("op_count", "<i4"),
+                          ("edit_dist", "<i4"), ("reserved", "<i4")])
+MAP_OP_DTYPE = np.dtype([("len", "<i4"), ("code", "<i4")])
+
+
+def default_map_options(error_percent=0.08):
+    """mapOptions_t::initOptions (src/options.cpp:43-92) as alfa_map_options"""
+    o = MapOptions()
+    o.match, o.mismatch, o.open_gap, o.extend_gap = 1, -4, -6, -1
+    o.global_, o.fixed_band, o.max_trial, o.max_trial_best, o.max_aln_count, o.rescue = 1, 100, 10, 1, 5000, 1
+    o.mem_type, o.max_seed_candidates, o.max_smem_start, o.max_region_mems, o.min_mem_reg_length = SEED_SMAM, 10000, 10, 20, 50
+    o.cigar_alignments = 1
+    o.error_percent = error_percent
+    return o
+
+
+def make_map_reads(fw, rc, K, opt, min_mem=40, min_coverage=0.25):
+    """per-read records with the reference's length-dependent arithmetic (src/mapper.cpp:1224-1231, 1280-1287, 533-536)"""
+    n = len(fw)
+    arr = (MapRead * n)()
+    e = opt.error_percent
+    for i in range(n):
+        pl = len(fw[i])
+        ed = int(e * pl) + 1
+        min_len = min_mem
+        if pl >= 1000:
+            min_len = int(min_len + (20 * (pl // 500)) / (100 * e))
+        sq = max((min_len - 10) // K, 1) if K >= 4 else max((min_len - 12) // K, 1)
+        a = arr[i]
+        a.P, a.Prc, a.plen, a.min_len, a.sparse_q, a.edit_dist = fw[i], rc[i], pl, min_len, sq, ed
+        a.min_score = int(pl * opt.match + (opt.mismatch - opt.match) * ed)
+        a.min_coverage = int(pl * min_coverage)
+        a.min_score2 = max(0, int(pl * opt.match + (opt.mismatch - opt.match) * 0.2 * pl))
+        a.min_coverage2 = int(pl * 0.01)
+    return arr
+
+
+def map_reads_batch(dev_index, opt, params, reads):
+    """-> (status[n], aln_off[n+1], alignments, seed_off[n+1], chain seeds, op_off[n+1], CIGAR operations)"""
+    n = len(reads)
+    st = np.zeros(n, np.int32)
+    aoff = np.zeros(n + 1, np.int64)
+    soff = np.zeros(n + 1, np.int64)
+    ooff = np.zeros(n + 1, np.int64)
+    ap, sp, op = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    check(lib().alfa_map_reads_batch(dev_index._h, C.byref(opt), C.byref(params), reads, n, st.ctypes.data_as(C.c_void_p),
+                                     aoff.ctypes.data_as(C.c_void_p), C.byref(ap), soff.ctypes.data_as(C.c_void_p), C.byref(sp),
+                                     ooff.ctypes.data_as(C.c_void_p), C.byref(op)))
+    na, ns, no = int(aoff[-1]), int(soff[-1]), int(ooff[-1])
+    ops = np.frombuffer(C.string_at(op.value, no * MAP_OP_DTYPE.itemsize), dtype=MAP_OP_DTYPE).copy() if no else np.zeros(0, MAP_OP_DTYPE)
+    lib().alfa_free(op)
+    al = np.frombuffer(C.string_at(ap.value, na * MAP_ALN_DTYPE.itemsize), dtype=MAP_ALN_DTYPE).copy() if na else np.zeros(0, MAP_ALN_DTYPE)
+    sd = np.frombuffer(C.string_at(sp.value, ns * MATCH_DTYPE.itemsize), dtype=MATCH_DTYPE).copy() if ns else np.zeros(0, MATCH_DTYPE)
+    lib().alfa_free(ap)
+    lib().alfa_free(sp)
+    return st, aoff, al, soff, sd, ooff, ops

@@ -211,8 +211,10 @@ def mapper_dp_tasks(workdir, index_prefix, reads, threads=8, device=0, extra=())
         os.remove(old)
     exe = os.path.join(ROOT, "alfalfa_amd", "alfalfa_amd")
     env = dict(os.environ, ALFA_TASK_LOG=prefix)
+    # --host-trials: the trial loop on the host, so that every ksw call goes through the batch entry points and is logged (by
+    # default whole reads are mapped inside one kernel, alfa_map_reads_batch, and only ksw_global calls would show up)
     subprocess.run([exe, "align", "-i", index_prefix, "-0", fq, "-o", os.path.join(workdir, "step.sam"), "-t", str(threads),
-                    "--device", str(device)] + list(extra),
+                    "--device", str(device), "--host-trials"] + list(extra),
                    check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return load_task_log(prefix)
 

@@ -164,7 +164,8 @@ int  alfa_seed_regions_batch(alfa_index*, int mem_type, const alfa_seed_query* q
 typedef struct {
     int32_t match, mismatch, open_gap, extend_gap;     /* alnOptions values; the two gap penalties NEGATIVE as alnOptions holds them */
     int32_t global, fixed_band, max_trial, max_trial_best, max_aln_count, rescue;
-    int32_t mem_type, max_seed_candidates, max_smem_start, max_region_mems, min_mem_reg_length, reserved;
+    int32_t mem_type, max_seed_candidates, max_smem_start, max_region_mems, min_mem_reg_length;
+    int32_t cigar_alignments;           /* alnOptions.alignmentCount: extended CIGARs for that many alignments per read (0 = none) */
     double error_percent;
 } alfa_map_options;
 typedef struct {
@@ -175,9 +176,20 @@ typedef struct {
     int32_t min_score, min_coverage;    /* first pass                                                        :1281, :1282 */
     int32_t min_score2, min_coverage2;  /* second pass (looser thresholds, at most 20 alignments)            :1285-1287 */
 } alfa_map_read;
-typedef struct { int64_t ref_begin, ref_end; int32_t q_begin, q_end, score, forward, chain_first, chain_count; } alfa_map_alignment;
+typedef struct {
+    int64_t ref_begin, ref_end; int32_t q_begin, q_end, score, forward, chain_first, chain_count;
+    int32_t op_first, op_count, edit_dist, reserved;   /* the extended CIGAR, when it was made with the alignment: see below */
+} alfa_map_alignment;
+/* CIGAR recovery (read_t::postprocess src/mapper.cpp:322-358 -> constructCIGAR :172-271 -> ksw_global + recoverCIGAR4 :80-117)
+ * for the o->cigar_alignments best-scoring alignments of a read (ties as std::sort leaves them), in the same kernel: alignment a
+ * with op_count >= 0 owns (*ops)[op_off[i] + a.op_first .. + a.op_count), the operations of its X0:Z tag in order -- `code` is
+ * the character ('=', 'X', 'I', 'D', 'S'), `len` the number in front of it exactly as the reference prints it (the closed-form
+ * gap cases can print 0 or negative lengths) -- and edit_dist is its NM.  op_count == -1: not made here (not among the best, a
+ * degenerate ksw_global call, a capacity); the caller runs constructCIGAR through alfa_ksw_global_batch as before. */
+typedef struct { int32_t len, code; } alfa_map_cigar_op;
 int  alfa_map_reads_batch(alfa_index*, const alfa_map_options* o, const alfa_dp_params* dp, const alfa_map_read* reads, int n,
-                          int32_t* status, int64_t* aln_off, alfa_map_alignment** alns, int64_t* seed_off, alfa_match** seeds);
+                          int32_t* status, int64_t* aln_off, alfa_map_alignment** alns, int64_t* seed_off, alfa_match** seeds,
+                          int64_t* op_off, alfa_map_cigar_op** ops);
 
 /* --- banded DP ---------------------------------------------------------- */
 /* replaces: ksw_extend(...)  src/ksw.h:106 / src/ksw.c:362 */

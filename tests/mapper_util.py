@@ -273,13 +273,14 @@ def write_c4(d, n=C4_READS):
     return ref, reads
 
 
-def run_c4(exe, d, threads="16", index_args=(), env=None):
+def run_c4(exe, d, threads="16", index_args=(), env=None, extra=(), tag=""):
     pre = os.path.join(d, "c4idx_%s" % os.path.basename(exe))
     if not os.path.exists(pre + ".aux"):
         subprocess.run([exe, "index", "-r", "c4.fa", "-p", pre, "-s", "12"] + list(index_args), cwd=d, check=True, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL)
-    out = os.path.join(d, "c4_%s.sam" % os.path.basename(exe))
-    p = subprocess.run([exe, "align", "-i", pre, "-0", "c4.fq", "-o", out, "-t", threads] + C4_ARGS, cwd=d, stdout=subprocess.PIPE,
+    out = os.path.join(d, "c4_%s%s.sam" % (os.path.basename(exe), tag))
+    p = subprocess.run([exe, "align", "-i", pre, "-0", "c4.fq", "-o", out, "-t", threads] + C4_ARGS + list(extra), cwd=d, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, env=env)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
+    run_c4.last_stderr = p.stderr.decode()
     return sam_body(out)

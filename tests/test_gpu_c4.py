@@ -95,12 +95,19 @@ def test_c4_cli_vs_reference_md5_and_its_dp_tasks_vs_oracle(c4, gpu):
     import bench
     d, ref, reads = c4
     gold = json.load(open(os.path.join(G.GOLD, "c4_md5.json")))
-    prefix = os.path.join(d, "c4tasks")
-    env = dict(os.environ, ALFA_TASK_LOG=prefix)
-    body = M.run_c4(M.GPU_EXE, d, threads="16", index_args=["--gpu-index"], env=env)
+    # the default path: whole reads mapped on the device (alfa_map_reads_batch), reads it hands back through the batch calls
+    body = M.run_c4(M.GPU_EXE, d, threads="16", index_args=["--gpu-index"], extra=["--stats"])
     recs = [l for l in body.split(b"\n") if l and not l.startswith(b"@")]
     assert len(recs) == gold["records"]
     assert sum(1 for l in recs if not (int(l.split(b"\t")[1]) & 4)) == gold["mapped"]
+    assert M.md5(body) == gold["md5"]
+    import re
+    m = re.search(r"#CORE reads_done (\d+) handed_back (\d+)", M.run_c4.last_stderr)
+    assert m and int(m.group(1)) + int(m.group(2)) == len(reads)
+    # the trial loop on the host (--host-trials): every DP call goes through the batch entry points and is logged
+    prefix = os.path.join(d, "c4tasks")
+    env = dict(os.environ, ALFA_TASK_LOG=prefix)
+    body = M.run_c4(M.GPU_EXE, d, threads="16", index_args=["--gpu-index"], env=env, extra=["--host-trials"], tag="_host")
     assert M.md5(body) == gold["md5"]
     # the DP tasks of that run
     tk = bench.load_task_log(prefix)
