@@ -1783,8 +1783,8 @@ struct alfa_seed_plan {
     alfa::DevBuf d_reads, d_q, d_tot, d_base, d_work, d_cnt, d_out, d_tmp, d_scr, d_q3;
     alfa::DevBuf d_reg, d_rm, d_chain, d_aux;     // alfa_seed_regions_batch: regions, their members, first chains, per-strand ints
     // alfa_map_reads_batch: per-read parameters and strand offsets, DP scratch, slotted and dense results, scoring parameters
-    alfa::DevBuf d_mrp, d_moff, d_mscr, d_mint, d_maln, d_mseed, d_maln2, d_mseed2, d_mprm, d_mtmp, d_mz, d_mops, d_mops2;
-    alfa::PinBuf h_mint;
+    alfa::DevBuf d_marena;
+    alfa::PinBuf h_mint, h_mstage;
     hipEvent_t mev0 = nullptr, mev1 = nullptr;
     size_t tmp_bytes = 0;
     int mem_type = ALFA_SEED_SMAM;
@@ -2087,8 +2087,8 @@ void plan_release(alfa_seed_plan* pl) {
     pl->d_reads.release(); pl->d_q.release(); pl->d_tot.release(); pl->d_base.release(); pl->d_work.release(); pl->d_out.release();
     pl->d_tmp.release(); pl->d_scr.release(); pl->d_cnt.release(); pl->d_q3.release();
     pl->d_reg.release(); pl->d_rm.release(); pl->d_chain.release(); pl->d_aux.release();
-    for (alfa::DevBuf* b : {&pl->d_mrp, &pl->d_moff, &pl->d_mscr, &pl->d_mint, &pl->d_maln, &pl->d_mseed, &pl->d_maln2, &pl->d_mseed2, &pl->d_mprm, &pl->d_mtmp, &pl->d_mz, &pl->d_mops, &pl->d_mops2}) b->release();
-    pl->h_mint.release();
+    pl->d_marena.release();
+    pl->h_mint.release(); pl->h_mstage.release();
     if (pl->mev0) { (void)hipEventDestroy(pl->mev0); (void)hipEventDestroy(pl->mev1); pl->mev0 = pl->mev1 = nullptr; }
     for (alfa::DevBuf* b : {&pl->d_qbase, &pl->d_keys, &pl->d_keys2, &pl->d_vals, &pl->d_vals2, &pl->d_fcnt, &pl->d_fscan, &pl->d_frec, &pl->d_sorttmp}) b->release();
     if (pl->ev0) { (void)hipEventDestroy(pl->ev0); (void)hipEventDestroy(pl->ev1); pl->ev0 = pl->ev1 = nullptr; }
@@ -2327,33 +2327,42 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     // else what 256 MiB per call give (at least 16 KiB: 128 rows of a band of up to 128 diagonals); a longer piece's CIGAR
     // is left to the caller (op_count = -1)
     const int64_t zworst = 256 * ((int64_t)max_plen + max_edit + 8);
-    const int64_t zstride = o->cigar_alignments > 0 ? std::min(zworst, std::max<int64_t>(16 << 10, (((int64_t)256 << 20) / n) & ~(int64_t)255)) : 0;
+    const int64_t zstride = o->cigar_alignments > 0 ? std::min(zworst, std::max<int64_t>(16 << 10, (((int64_t)64 << 20) / n) & ~(int64_t)255)) : 0;
     size_t tmp_bytes = 0;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int32_t*)nullptr, (int32_t*)nullptr, n + 1, st));
-    if ((rc = pl->d_mrp.reserve(sizeof(alfa::mapcore::ReadParams) * (size_t)n)) || (rc = pl->d_moff.reserve(8 * ((size_t)nq + 1))) ||
-        (rc = pl->d_mscr.reserve((size_t)stride64 * (size_t)n + 64)) || (rc = pl->d_mint.reserve(4 * (nints + 8))) ||
-        (rc = pl->d_maln.reserve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP)) || (rc = pl->d_mseed.reserve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP)) ||
-        (rc = pl->d_maln2.reserve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP)) || (rc = pl->d_mseed2.reserve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP)) ||
-        (rc = pl->d_mprm.reserve(sizeof(DevParams))) || (rc = pl->d_mtmp.reserve(tmp_bytes + 64)) || (rc = pl->h_mint.reserve(4 * (nints + 8))) ||
-        (rc = pl->d_mz.reserve((size_t)zstride * (size_t)n + 64)) || (rc = pl->d_mops.reserve(sizeof(alfa::mapcore::CigOp) * (size_t)n * OPS_CAP)) ||
-        (rc = pl->d_mops2.reserve(sizeof(alfa::mapcore::CigOp) * (size_t)n * OPS_CAP)) ||
-        (rc = cx->h_in2.reserve(sizeof(alfa::mapcore::ReadParams) * (size_t)n + sizeof(DevParams) + 64)))
-        return rc;
+    // ONE device arena and ONE pinned arena per calling thread for everything below (each hipMalloc / hipHostMalloc is a trip
+    // through the runtime's allocator lock, and sixteen worker threads make their first calls at the same moment)
+    size_t dsz = 0;
+    auto carve = [&](size_t bytes) { const size_t at = dsz; dsz += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_rp = carve(sizeof(alfa::mapcore::ReadParams) * (size_t)n), o_off = carve(8 * ((size_t)nq + 1)), o_prm = carve(sizeof(DevParams));
+    const size_t o_int = carve(4 * (nints + 8)), o_tmp = carve(tmp_bytes + 64);
+    const size_t o_aln = carve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP), o_aln2 = carve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP);
+    const size_t o_seed = carve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP), o_seed2 = carve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP);
+    const size_t o_ops = carve(sizeof(alfa::mapcore::CigOp) * (size_t)n * OPS_CAP), o_ops2 = carve(sizeof(alfa::mapcore::CigOp) * (size_t)n * OPS_CAP);
+    const size_t o_scr = carve((size_t)stride64 * (size_t)n + 64), o_z = carve((size_t)zstride * (size_t)n + 64);
+    // pinned: [ReadParams n | DevParams | strand offsets 2n+1 | the int block] ; the dense results are staged in a second pinned buffer
+    size_t hsz = 0;
+    auto hcarve = [&](size_t bytes) { const size_t at = hsz; hsz += (bytes + 63) & ~(size_t)63; return at; };
+    const size_t p_rp = hcarve(sizeof(alfa::mapcore::ReadParams) * (size_t)n), p_prm = hcarve(sizeof(DevParams)), p_off = hcarve(8 * ((size_t)nq + 1));
+    const size_t p_int = hcarve(4 * (nints + 8));
+    if ((rc = pl->d_marena.reserve(dsz)) || (rc = pl->h_mint.reserve(hsz))) return rc;
+    char* const dA = pl->d_marena.as<char>();
+    char* const hA = pl->h_mint.as<char>();
     if (!pl->mev0) { ALFA_HIP(hipEventCreate(&pl->mev0)); ALFA_HIP(hipEventCreate(&pl->mev1)); }
     {
-        alfa::mapcore::ReadParams* hr = cx->h_in2.as<alfa::mapcore::ReadParams>();
+        alfa::mapcore::ReadParams* hr = (alfa::mapcore::ReadParams*)(hA + p_rp);
         for (int i = 0; i < n; ++i) {
             const alfa_map_read& r = reads[i];
             hr[i].plen = r.plen; hr[i].editDist = r.edit_dist; hr[i].minScore = r.min_score; hr[i].minCoverage = r.min_coverage;
             hr[i].minScore2 = r.min_score2; hr[i].minCoverage2 = r.min_coverage2;
         }
-        DevParams* hp = (DevParams*)(hr + n);
-        dev_params_from(*dp, *hp);
-        ALFA_HIP(hipMemcpyAsync(pl->d_mrp.p, hr, sizeof(alfa::mapcore::ReadParams) * (size_t)n, hipMemcpyHostToDevice, st));
-        ALFA_HIP(hipMemcpyAsync(pl->d_mprm.p, hp, sizeof(DevParams), hipMemcpyHostToDevice, st));
-        ALFA_HIP(hipMemcpyAsync(pl->d_moff.p, h_off.data(), 8 * (size_t)nq, hipMemcpyHostToDevice, st));
+        dev_params_from(*dp, *(DevParams*)(hA + p_prm));
+        memcpy(hA + p_off, h_off.data(), 8 * (size_t)nq);
+        ALFA_HIP(hipMemcpyAsync(dA + o_rp, hA + p_rp, sizeof(alfa::mapcore::ReadParams) * (size_t)n, hipMemcpyHostToDevice, st));
+        ALFA_HIP(hipMemcpyAsync(dA + o_prm, hA + p_prm, sizeof(DevParams), hipMemcpyHostToDevice, st));
+        ALFA_HIP(hipMemcpyAsync(dA + o_off, hA + p_off, 8 * (size_t)nq, hipMemcpyHostToDevice, st));
     }
-    int32_t* d_int = pl->d_mint.as<int32_t>();
+    int32_t* d_int = (int32_t*)(dA + o_int);
     int32_t* d_status = d_int;
     int32_t* d_naln = d_int + n;                     // n + 1 entries, the last stays 0
     int32_t* d_nseed = d_naln + (n + 1);
@@ -2364,32 +2373,31 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     ALFA_HIP(hipMemsetAsync(d_int, 0, 4 * (nints + 8), st));
     alfa::MapKernelArgs A;
     A.S = ix->S.as<uint8_t>() + PADB; A.N = ix->N; A.startpos = ix->STARTPOS.as<int64_t>(); A.n_seq = ix->n_seq;
-    A.reads = pl->d_reads.as<uint8_t>(); A.read_off = pl->d_moff.as<int64_t>(); A.rp = pl->d_mrp.as<alfa::mapcore::ReadParams>(); A.n = n;
+    A.reads = pl->d_reads.as<uint8_t>(); A.read_off = (const int64_t*)(dA + o_off); A.rp = (const alfa::mapcore::ReadParams*)(dA + o_rp); A.n = n;
     A.base = pl->d_base.as<int64_t>(); A.reg = pl->d_reg.as<alfa_region>(); A.members = pl->d_rm.as<alfa_match>();
     A.nreg = d_aux + 2 * (size_t)nq; A.rstatus = d_aux + 4 * (size_t)nq;
-    A.dp_params = pl->d_mprm.p; A.scratch = pl->d_mscr.as<uint8_t>(); A.scratch_stride = (int32_t)stride64; A.qcap = qcap;
-    A.zscratch = pl->d_mz.as<uint8_t>(); A.zstride = zstride;
+    A.dp_params = dA + o_prm; A.scratch = (uint8_t*)(dA + o_scr); A.scratch_stride = (int32_t)stride64; A.qcap = qcap;
+    A.zscratch = (uint8_t*)(dA + o_z); A.zstride = zstride;
     A.opt.cigarCount = o->cigar_alignments > 0 ? o->cigar_alignments : 0; A.opt.pad_ = 0;
     A.opt.match = o->match; A.opt.mismatch = o->mismatch; A.opt.openGap = o->open_gap; A.opt.extendGap = o->extend_gap;
     A.opt.global = o->global; A.opt.fixedBandSize = o->fixed_band; A.opt.maxTrial = o->max_trial; A.opt.maxTrialBest = o->max_trial_best;
     A.opt.maxAlnCount = o->max_aln_count; A.opt.rescue = o->rescue; A.opt.errorPercent = o->error_percent;
     A.status = d_status; A.naln = d_naln; A.nseed = d_nseed; A.nops = d_nops;
-    A.alns = pl->d_maln.as<alfa::mapcore::AlnOut>(); A.seeds = pl->d_mseed.as<alfa_match>(); A.ops = pl->d_mops.as<alfa::mapcore::CigOp>();
+    A.alns = (alfa::mapcore::AlnOut*)(dA + o_aln); A.seeds = (alfa_match*)(dA + o_seed); A.ops = (alfa::mapcore::CigOp*)(dA + o_ops);
     ALFA_HIP(hipEventRecord(pl->mev0, st));
     alfa::launch_map(st, A);
     ALFA_HIP(hipGetLastError());
     ALFA_HIP(hipEventRecord(pl->mev1, st));
     size_t tb = tmp_bytes;
-    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_mtmp.p, tb, d_naln, d_aoff, n + 1, st));
+    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(dA + o_tmp, tb, d_naln, d_aoff, n + 1, st));
     tb = tmp_bytes;
-    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_mtmp.p, tb, d_nseed, d_soff, n + 1, st));
+    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(dA + o_tmp, tb, d_nseed, d_soff, n + 1, st));
     tb = tmp_bytes;
-    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(pl->d_mtmp.p, tb, d_nops, d_ooff, n + 1, st));
-    alfa::launch_map_compact(st, n, d_naln, d_nseed, d_nops, d_aoff, d_soff, d_ooff, pl->d_maln.as<alfa::mapcore::AlnOut>(), pl->d_mseed.as<alfa_match>(),
-                             pl->d_mops.as<alfa::mapcore::CigOp>(), pl->d_maln2.as<alfa::mapcore::AlnOut>(), pl->d_mseed2.as<alfa_match>(),
-                             pl->d_mops2.as<alfa::mapcore::CigOp>());
+    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(dA + o_tmp, tb, d_nops, d_ooff, n + 1, st));
+    alfa::launch_map_compact(st, n, d_naln, d_nseed, d_nops, d_aoff, d_soff, d_ooff, A.alns, A.seeds, A.ops, (alfa::mapcore::AlnOut*)(dA + o_aln2),
+                             (alfa_match*)(dA + o_seed2), (alfa::mapcore::CigOp*)(dA + o_ops2));
     ALFA_HIP(hipGetLastError());
-    int32_t* h_int = pl->h_mint.as<int32_t>();
+    int32_t* h_int = (int32_t*)(hA + p_int);
     ALFA_HIP(hipMemcpyAsync(h_int, d_int, 4 * nints, hipMemcpyDeviceToHost, st));
     const double ms_enq = since(tc0) - ms_fill - ms_seeds;
     ALFA_HIP(hipStreamSynchronize(st));
@@ -2403,16 +2411,23 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     const int64_t ta = aln_off[n], ts = seed_off[n], to = op_off[n];
     alfa_map_cigar_op* ho = (alfa_map_cigar_op*)realloc(*ops, sizeof(alfa_map_cigar_op) * (size_t)(to + 1));
     if (ho) *ops = ho;
-    else return alfa::fail(ALFA_ENOMEM, "out of host memory for the CIGAR operations");
-    if (to > 0) ALFA_HIP(hipMemcpyAsync(ho, pl->d_mops2.p, sizeof(alfa_map_cigar_op) * (size_t)to, hipMemcpyDeviceToHost, st));
     alfa_map_alignment* ha = (alfa_map_alignment*)realloc(*alns, sizeof(alfa_map_alignment) * (size_t)(ta + 1));
     if (ha) *alns = ha;
     alfa_match* hs = (alfa_match*)realloc(*seeds, sizeof(alfa_match) * (size_t)(ts + 1));
     if (hs) *seeds = hs;
-    if (!ha || !hs) return alfa::fail(ALFA_ENOMEM, "out of host memory for the alignments");
-    if (ta > 0) ALFA_HIP(hipMemcpyAsync(ha, pl->d_maln2.p, sizeof(alfa_map_alignment) * (size_t)ta, hipMemcpyDeviceToHost, st));
-    if (ts > 0) ALFA_HIP(hipMemcpyAsync(hs, pl->d_mseed2.p, sizeof(alfa_match) * (size_t)ts, hipMemcpyDeviceToHost, st));
+    if (!ha || !hs || !ho) return alfa::fail(ALFA_ENOMEM, "out of host memory for the alignments");
+    // the dense results come back through pinned staging (a copy into pageable memory is staged by the runtime anyway, under
+    // its own locks) and are handed out in malloc'd arrays, as the header promises
+    const size_t ba = sizeof(alfa_map_alignment) * (size_t)ta, bs = sizeof(alfa_match) * (size_t)ts, bo = sizeof(alfa_map_cigar_op) * (size_t)to;
+    if ((rc = pl->h_mstage.reserve(ba + bs + bo + 64))) return rc;
+    char* hS = pl->h_mstage.as<char>();
+    if (ta > 0) ALFA_HIP(hipMemcpyAsync(hS, dA + o_aln2, ba, hipMemcpyDeviceToHost, st));
+    if (ts > 0) ALFA_HIP(hipMemcpyAsync(hS + ba, dA + o_seed2, bs, hipMemcpyDeviceToHost, st));
+    if (to > 0) ALFA_HIP(hipMemcpyAsync(hS + ba + bs, dA + o_ops2, bo, hipMemcpyDeviceToHost, st));
     ALFA_HIP(hipStreamSynchronize(st));
+    if (ta > 0) memcpy(ha, hS, ba);
+    if (ts > 0) memcpy(hs, hS + ba, bs);
+    if (to > 0) memcpy(ho, hS + ba + bs, bo);
     float ms = 0;
     if (hipEventElapsedTime(&ms, pl->mev0, pl->mev1) != hipSuccess) { (void)hipGetLastError(); ms = 0; }
     alfa::g_last_timing.kernel_ms = ms;

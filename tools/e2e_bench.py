@@ -90,7 +90,13 @@ def main():
         t0 = time.time()
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         dt = time.time() - t0
-        stats = [l for l in p.stderr.decode().split("\n") if l.startswith(("#STATS", "#PHASES", "#WORKERS", "#STARTUP"))]
+        stats = [l for l in p.stderr.decode().split("\n") if l.startswith(("#STATS", "#PHASES", "#WORKERS", "#STARTUP", "#CORE"))]
+        calls = [l for l in p.stderr.decode().split("\n") if l.startswith("#MAPCALL")]
+        if calls:      # ALFA_CALL_LOG=1: where the whole-read device calls spend their time (sums over all calls, milliseconds)
+            import re
+            keys = ["fill_ms", "seeds_ms", "enqueue_ms", "regions_map_wait_ms", "total_ms", "map_kernel_ms", "seed_kernel_ms"]
+            tot = {k: sum(float(re.search(k + r" ([0-9.]+)", l).group(1)) for l in calls) for k in keys}
+            stats.append("#MAPCALLS n=%d " % len(calls) + " ".join("%s %.1f" % (k, tot[k]) for k in keys))
         import hashlib
         body = b"\n".join(l for l in open(out, "rb").read().split(b"\n") if not l.startswith(b"@PG"))
         md5s[name] = hashlib.md5(body).hexdigest()
