@@ -34,7 +34,7 @@ constexpr int TREE_CAP = 128;       // distinct read positions in hasUnique's in
 constexpr int BOUND_CAP = 24;       // chains tried in one region (alnBounds)
 constexpr int ALN_CAP = 8;          // alignments reported per read
 constexpr int CHAINOUT_CAP = 96;    // seeds of all reported chains of a read
-constexpr int OPS_CAP = 160;        // extended CIGAR operations of a read's reported alignments
+constexpr int OPS_CAP = 160;        // extended CIGAR operations of a read's reported alignments: the least a caller provides room for
 constexpr int BAM_CAP = 96;         // BAM CIGAR operations of one ksw_global call
 
 enum Status { DONE = 0, NEED_CALLER = 1 };      // NEED_CALLER: the caller maps this read itself (a capacity was exceeded, the
@@ -76,7 +76,8 @@ struct Work {                       // one read's state (LDS on the device)
     AlnOut alns[ALN_CAP];                           // the read's alignments, in the order the reference appends them
     int64_t cref[CHAINOUT_CAP];                     // their chains' seeds
     int32_t cq[CHAINOUT_CAP], cl[CHAINOUT_CAP];
-    CigOp ops[OPS_CAP];
+    CigOp* ops;                                     // the read's extended CIGAR operations (caller's memory: written, never read back)
+    int32_t opsCap;
     uint32_t bam[BAM_CAP];
     uint16_t aorder[ALN_CAP];
     int32_t nAln, nChainOut, nOps, fail;
@@ -390,7 +391,7 @@ MC_FN int band_estimate(int fixedBand, int qLen, int refLen, int matchScore, int
 }
 
 MC_FN bool push_op(Work& W, int32_t len, char code) {
-    if (W.nOps >= OPS_CAP) return false;
+    if (W.nOps >= W.opsCap) return false;
     CigOp o; o.len = len; o.code = (int32_t)code;
     W.ops[W.nOps++] = o;
     return true;

@@ -42,7 +42,8 @@ struct MapKernelArgs {
     int32_t* nops;                  // [n]
     mapcore::AlnOut* alns;          // [n * ALN_CAP]
     alfa_match* seeds;              // [n * CHAINOUT_CAP]
-    mapcore::CigOp* ops;            // [n * OPS_CAP]
+    mapcore::CigOp* ops;            // [n * ops_cap]
+    int32_t ops_cap;                // room for a read's CIGAR operations (>= mapcore::OPS_CAP)
 };
 
 void launch_map(hipStream_t st, const MapKernelArgs& a);
@@ -50,6 +51,6 @@ void launch_map(hipStream_t st, const MapKernelArgs& a);
 // its CIGAR operations to out_ops[op_off[r] ..]
 void launch_map_compact(hipStream_t st, int n, const int32_t* naln, const int32_t* nseed, const int32_t* nops, const int32_t* aln_off,
                         const int32_t* seed_off, const int32_t* op_off, const mapcore::AlnOut* alns, const alfa_match* seeds,
-                        const mapcore::CigOp* ops, mapcore::AlnOut* out_alns, alfa_match* out_seeds, mapcore::CigOp* out_ops);
+                        const mapcore::CigOp* ops, int ops_cap, mapcore::AlnOut* out_alns, alfa_match* out_seeds, mapcore::CigOp* out_ops);
 
 }  // namespace alfa

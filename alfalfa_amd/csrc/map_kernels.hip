@@ -203,6 +203,8 @@ __global__ __launch_bounds__(64) void map_kernel(const MapKernelArgs A) {
         if (nreg > mapcore::REGION_CAP2) status = mapcore::NEED_CALLER;
         else {
             for (int k = ln; k < nreg; k += 64) W.rscore[k] = k < env.nF ? env.regF[k].score : env.regR[k - env.nF].score;
+            W.ops = A.ops + (int64_t)r * A.ops_cap;          // (every lane stores the same two values)
+            W.opsCap = A.ops_cap;
             __syncthreads();
             status = mapcore::map_read(env, W, A.opt, A.rp[r], nreg);
             if (status == mapcore::DONE) {
@@ -213,7 +215,6 @@ __global__ __launch_bounds__(64) void map_kernel(const MapKernelArgs A) {
                     alfa_match m; m.ref = W.cref[k]; m.query = W.cq[k]; m.len = W.cl[k];
                     A.seeds[(int64_t)r * mapcore::CHAINOUT_CAP + k] = m;
                 }
-                for (int k = ln; k < nops; k += 64) A.ops[(int64_t)r * mapcore::OPS_CAP + k] = W.ops[k];
             }
         }
     }
@@ -227,14 +228,14 @@ __global__ __launch_bounds__(64) void map_kernel(const MapKernelArgs A) {
 
 __global__ void map_compact_kernel(int n, const int32_t* __restrict__ naln, const int32_t* __restrict__ nseed, const int32_t* __restrict__ nops,
                                    const int32_t* __restrict__ aln_off, const int32_t* __restrict__ seed_off, const int32_t* __restrict__ op_off,
-                                   const AlnOut* __restrict__ alns, const alfa_match* __restrict__ seeds, const mapcore::CigOp* __restrict__ ops,
+                                   const AlnOut* __restrict__ alns, const alfa_match* __restrict__ seeds, const mapcore::CigOp* __restrict__ ops, int ops_cap,
                                    AlnOut* __restrict__ out_alns, alfa_match* __restrict__ out_seeds, mapcore::CigOp* __restrict__ out_ops) {
     const int r = blockIdx.x;
     if (r >= n) return;
     const int na = naln[r], ns = nseed[r], no = nops[r];
     for (int k = threadIdx.x; k < na; k += blockDim.x) out_alns[aln_off[r] + k] = alns[(int64_t)r * mapcore::ALN_CAP + k];
     for (int k = threadIdx.x; k < ns; k += blockDim.x) out_seeds[seed_off[r] + k] = seeds[(int64_t)r * mapcore::CHAINOUT_CAP + k];
-    for (int k = threadIdx.x; k < no; k += blockDim.x) out_ops[op_off[r] + k] = ops[(int64_t)r * mapcore::OPS_CAP + k];
+    for (int k = threadIdx.x; k < no; k += blockDim.x) out_ops[op_off[r] + k] = ops[(int64_t)r * ops_cap + k];
 }
 
 }  // namespace
@@ -246,10 +247,10 @@ void launch_map(hipStream_t st, const MapKernelArgs& a) {
 
 void launch_map_compact(hipStream_t st, int n, const int32_t* naln, const int32_t* nseed, const int32_t* nops, const int32_t* aln_off,
                         const int32_t* seed_off, const int32_t* op_off, const mapcore::AlnOut* alns, const alfa_match* seeds,
-                        const mapcore::CigOp* ops, mapcore::AlnOut* out_alns, alfa_match* out_seeds, mapcore::CigOp* out_ops) {
+                        const mapcore::CigOp* ops, int ops_cap, mapcore::AlnOut* out_alns, alfa_match* out_seeds, mapcore::CigOp* out_ops) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(map_compact_kernel, dim3(n), dim3(64), 0, st, n, naln, nseed, nops, aln_off, seed_off, op_off, alns, seeds, ops, out_alns,
-                       out_seeds, out_ops);
+    hipLaunchKernelGGL(map_compact_kernel, dim3(n), dim3(64), 0, st, n, naln, nseed, nops, aln_off, seed_off, op_off, alns, seeds, ops, ops_cap,
+                       out_alns, out_seeds, out_ops);
 }
 
 }  // namespace alfa

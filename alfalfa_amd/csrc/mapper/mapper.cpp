@@ -825,6 +825,8 @@ bool Mapper::core_trials(Read& read, const std::vector<Lis>& lis) {
     for (const Lis& l : lis) view.push_back(Mapper_Lis_view{&l.matches, l.fw, l.score});
     CoreEnv env{idx_, hot_, read, &view};
     std::unique_ptr<mapcore::Work> W(new mapcore::Work());
+    std::vector<mapcore::CigOp> opbuf((size_t)std::max<size_t>(mapcore::OPS_CAP, read.sequence.length() + 64));
+    W->ops = opbuf.data(); W->opsCap = (int32_t)opbuf.size();
     if (lis.size() > (size_t)mapcore::REGION_CAP2) return false;
     for (size_t k = 0; k < lis.size(); ++k) W->rscore[k] = lis[k].score;
     const mapcore::Options O = core_options(opt_);

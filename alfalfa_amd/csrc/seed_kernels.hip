@@ -36,6 +36,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "device_ctx.h"
@@ -1836,48 +1837,80 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
         return rc;
     uint8_t* hp = cx->h_in.as<uint8_t>();
     SeedQ* hq = cx->h_tasks.as<SeedQ>();
-    size_t po = PADB;
     memset(hp, 0, PADB);
     bool magic_ok = true;       // every read short enough for the exact multiply-high prefix mapping (< 65536 prefixes)
     int64_t total_pref = 0, scr_ints = 0;
     int max_w = 0;
-    for (int i = 0; i < nq; ++i) {
-        SeedQ& s = hq[i];
-        s.poff = (int64_t)po;
-        s.plen = q[i].plen; s.min_len = q[i].min_len; s.max_count = q[i].max_count; s.sparse_q = q[i].sparse_q;
-        const int64_t np = smem_like ? count_prefixes_smem(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q)
-                                                      : count_prefixes(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q);
-        if (np < 0 || np > 0x3fffffff) return alfa::fail(ALFA_EINVAL, "seed query has too many prefixes");
-        s.npref = (int32_t)np;
-        {   // mirrors the device PrefixMap
-            const int64_t stp = (int64_t)q[i].sparse_q * ix->K;
-            const int64_t Lm = (int64_t)q[i].plen - (q[i].min_len - (stp - 1));
-            const int64_t nh = Lm >= 0 ? Lm / stp + 1 : 0;
-            const int64_t kk = std::min<int64_t>(ix->K, Lm + 1), rr = Lm >= 0 ? Lm % stp : 0;
-            s.pm_nh = (int32_t)nh;
-            s.pm_kh = (int32_t)std::min<int64_t>(kk, rr + 1);
-            s.pm_m1 = s.pm_m2 = 0;
-            if (np >= 65536 || nh >= 65536) magic_ok = false;
-            if (np < 65536 && nh >= 2 && nh < 65536) {
-                s.pm_m1 = (uint32_t)((0x100000000ull + (uint64_t)nh - 1) / (uint64_t)nh);
-                if (nh >= 3) s.pm_m2 = (uint32_t)((0x100000000ull + (uint64_t)(nh - 1) - 1) / (uint64_t)(nh - 1));
+    // offsets first (a running sum), then the descriptors and the read bytes -- the bulk of a call's host time (about 50 ns per
+    // read strand) -- in slices on a few threads when the call is large: one caller packing 200 000 strands is the case the
+    // PCIe-inclusive figure measures; the mapper's workers, which already pack their own slices side by side, stay below it
+    {
+        size_t po = PADB;
+        for (int i = 0; i < nq; ++i) { hq[i].poff = (int64_t)po; po += (size_t)q[i].plen; }
+    }
+    struct Part { int64_t total_pref = 0; int max_w = 0; bool magic_ok = true; int err = 0; };
+    auto pack_range = [&](int lo, int hi, Part& P) {
+        for (int i = lo; i < hi; ++i) {
+            SeedQ& s = hq[i];
+            const size_t po = (size_t)s.poff;
+            s.plen = q[i].plen; s.min_len = q[i].min_len; s.max_count = q[i].max_count; s.sparse_q = q[i].sparse_q;
+            const int64_t np = smem_like ? count_prefixes_smem(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q)
+                                                          : count_prefixes(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q);
+            if (np < 0 || np > 0x3fffffff) { P.err = 1; return; }
+            s.npref = (int32_t)np;
+            {   // mirrors the device PrefixMap
+                const int64_t stp = (int64_t)q[i].sparse_q * ix->K;
+                const int64_t Lm = (int64_t)q[i].plen - (q[i].min_len - (stp - 1));
+                const int64_t nh = Lm >= 0 ? Lm / stp + 1 : 0;
+                const int64_t kk = std::min<int64_t>(ix->K, Lm + 1), rr = Lm >= 0 ? Lm % stp : 0;
+                s.pm_nh = (int32_t)nh;
+                s.pm_kh = (int32_t)std::min<int64_t>(kk, rr + 1);
+                s.pm_m1 = s.pm_m2 = 0;
+                if (np >= 65536 || nh >= 65536) P.magic_ok = false;
+                if (np < 65536 && nh >= 2 && nh < 65536) {
+                    s.pm_m1 = (uint32_t)((0x100000000ull + (uint64_t)nh - 1) / (uint64_t)nh);
+                    if (nh >= 3) s.pm_m2 = (uint32_t)((0x100000000ull + (uint64_t)(nh - 1) - 1) / (uint64_t)(nh - 1));
+                }
+            }
+            s.max_smem = q[i].max_smem_cont;
+            s.soff = 0;
+            P.max_w = std::max(P.max_w, (int)std::max<int64_t>(q[i].plen, np) + 2);
+            P.total_pref += np;
+            if (q[i].plen) {
+                memcpy(hp + po, q[i].P, (size_t)q[i].plen);
+                if (memchr(q[i].P, 0, (size_t)q[i].plen)) {
+                    if (!ix->nul_sub) { P.err = 2; return; }
+                    for (int j = 0; j < q[i].plen; ++j)
+                        if (!hp[po + j]) hp[po + j] = ix->nul_sub;
+                }
             }
         }
-        s.max_smem = q[i].max_smem_cont;
-        s.soff = scr_ints;
-        const int w = (int)std::max<int64_t>(q[i].plen, np) + 2;
-        max_w = std::max(max_w, w);
-        if (smem_like) scr_ints += (int64_t)SMEM_TABLES * w;
-        total_pref += np;
-        if (q[i].plen) {
-            memcpy(hp + po, q[i].P, (size_t)q[i].plen);
-            if (memchr(q[i].P, 0, (size_t)q[i].plen)) {
-                if (!ix->nul_sub) return alfa::fail(ALFA_EINVAL, "a read contains a NUL byte and the text uses every other byte value");
-                for (int j = 0; j < q[i].plen; ++j)
-                    if (!hp[po + j]) hp[po + j] = ix->nul_sub;
-            }
+    };
+    {
+        static const int pack_threads = [] {
+            const char* e = getenv("ALFA_PACK_THREADS");
+            int t = e ? atoi(e) : (int)std::min<unsigned>(8, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));
+            return t < 1 ? 1 : (t > 32 ? 32 : t);
+        }();
+        const int nt = nq >= 32768 ? std::min(pack_threads, nq / 8192) : 1;
+        std::vector<Part> parts((size_t)std::max(nt, 1));
+        if (nt <= 1) pack_range(0, nq, parts[0]);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t) th.emplace_back([&, t] { pack_range((int)((int64_t)nq * t / nt), (int)((int64_t)nq * (t + 1) / nt), parts[(size_t)t]); });
+            pack_range(0, (int)((int64_t)nq / nt), parts[0]);
+            for (auto& x : th) x.join();
         }
-        po += (size_t)q[i].plen;
+        for (const Part& P : parts) {
+            if (P.err == 1) return alfa::fail(ALFA_EINVAL, "seed query has too many prefixes");
+            if (P.err == 2) return alfa::fail(ALFA_EINVAL, "a read contains a NUL byte and the text uses every other byte value");
+            total_pref += P.total_pref; max_w = std::max(max_w, P.max_w); magic_ok = magic_ok && P.magic_ok;
+        }
+        if (smem_like)            // per-read tables in the global scratch: a running sum over the reads
+            for (int i = 0; i < nq; ++i) {
+                hq[i].soff = scr_ints;
+                scr_ints += (int64_t)SMEM_TABLES * ((int)std::max<int64_t>(q[i].plen, hq[i].npref) + 2);
+            }
     }
     pl->total_pref = total_pref;
     pl->max_w = max_w;
@@ -2338,7 +2371,12 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     const size_t o_int = carve(4 * (nints + 8)), o_tmp = carve(tmp_bytes + 64);
     const size_t o_aln = carve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP), o_aln2 = carve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP);
     const size_t o_seed = carve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP), o_seed2 = carve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP);
-    const size_t o_ops = carve(sizeof(alfa::mapcore::CigOp) * (size_t)n * OPS_CAP), o_ops2 = carve(sizeof(alfa::mapcore::CigOp) * (size_t)n * OPS_CAP);
+    // a read's extended CIGAR: at 10 % error about one operation per five residues per reported alignment; room for one per two
+    // residues (more: op_count = -1 for that alignment, the caller recovers it), within 256 MiB per call
+    const int ops_cap = o->cigar_alignments > 0
+                            ? (int)std::max<int64_t>(OPS_CAP, std::min<int64_t>((int64_t)max_plen / 2 + 64, ((int64_t)256 << 20) / (8 * (int64_t)n)))
+                            : OPS_CAP;
+    const size_t o_ops = carve(sizeof(alfa::mapcore::CigOp) * (size_t)n * (size_t)ops_cap), o_ops2 = carve(sizeof(alfa::mapcore::CigOp) * (size_t)n * (size_t)ops_cap);
     const size_t o_scr = carve((size_t)stride64 * (size_t)n + 64), o_z = carve((size_t)zstride * (size_t)n + 64);
     // pinned: [ReadParams n | DevParams | strand offsets 2n+1 | the int block] ; the dense results are staged in a second pinned buffer
     size_t hsz = 0;
@@ -2383,7 +2421,7 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     A.opt.global = o->global; A.opt.fixedBandSize = o->fixed_band; A.opt.maxTrial = o->max_trial; A.opt.maxTrialBest = o->max_trial_best;
     A.opt.maxAlnCount = o->max_aln_count; A.opt.rescue = o->rescue; A.opt.errorPercent = o->error_percent;
     A.status = d_status; A.naln = d_naln; A.nseed = d_nseed; A.nops = d_nops;
-    A.alns = (alfa::mapcore::AlnOut*)(dA + o_aln); A.seeds = (alfa_match*)(dA + o_seed); A.ops = (alfa::mapcore::CigOp*)(dA + o_ops);
+    A.alns = (alfa::mapcore::AlnOut*)(dA + o_aln); A.seeds = (alfa_match*)(dA + o_seed); A.ops = (alfa::mapcore::CigOp*)(dA + o_ops); A.ops_cap = ops_cap;
     ALFA_HIP(hipEventRecord(pl->mev0, st));
     alfa::launch_map(st, A);
     ALFA_HIP(hipGetLastError());
@@ -2394,7 +2432,7 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(dA + o_tmp, tb, d_nseed, d_soff, n + 1, st));
     tb = tmp_bytes;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(dA + o_tmp, tb, d_nops, d_ooff, n + 1, st));
-    alfa::launch_map_compact(st, n, d_naln, d_nseed, d_nops, d_aoff, d_soff, d_ooff, A.alns, A.seeds, A.ops, (alfa::mapcore::AlnOut*)(dA + o_aln2),
+    alfa::launch_map_compact(st, n, d_naln, d_nseed, d_nops, d_aoff, d_soff, d_ooff, A.alns, A.seeds, A.ops, ops_cap, (alfa::mapcore::AlnOut*)(dA + o_aln2),
                              (alfa_match*)(dA + o_seed2), (alfa::mapcore::CigOp*)(dA + o_ops2));
     ALFA_HIP(hipGetLastError());
     int32_t* h_int = (int32_t*)(hA + p_int);

@@ -190,4 +190,4 @@ def test_cli_device_path_equals_host_trials_and_counts(gpu):
     body, err = M.run_synth(M.GPU_EXE, "synpe_strict_pairs", ["-t", "4", "--stats"])
     assert M.md5(body) == M.synth_md5("synpe_strict_pairs")
     m = re.search(r"#CORE reads_done (\d+) handed_back (\d+)", err)
-    assert m and int(m.group(1)) > 5000
+    assert m and int(m.group(1)) > 3500          # (a third of the second mates has no seed: the re-seeding rescue is handed back)
