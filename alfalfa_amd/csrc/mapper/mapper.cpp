@@ -66,45 +66,35 @@ struct RcTable {
 };
 const RcTable RC;
 
-// bandSizeEstimate src/mapper.cpp:44-52
-int band_estimate(int fixedBand, int qLen, int refLen, int matchScore, int gapOpen, int gapExtend, int alnScore) {
-    int minBand = std::max(qLen - refLen, refLen - qLen) + 3;
-    int scoreBand = (std::min(qLen, refLen) * matchScore - alnScore + gapOpen) / (-1 * gapExtend) + 1;
-    int maxGapBand = minBand - 3 + ((qLen >> 1) * matchScore + gapOpen) / (-1 * gapExtend) + 1;
-    int band = std::min(maxGapBand, scoreBand);
-    band = std::min(fixedBand, band);
-    band = std::max(minBand, band);
-    return band;
-}
+// bandSizeEstimate src/mapper.cpp:44-52: one restatement for the host and the device (csrc/map_core.h)
+using mapcore::band_estimate;
 
-// recoverCIGAR4 src/mapper.cpp:80-117 (also the body of setFieldsKsw :128-162)
+// recoverCIGAR4 src/mapper.cpp:80-117 (also the body of setFieldsKsw :128-162): a BAM CIGAR written out with its M runs split
+// into maximal stretches of equal ('=') and unequal ('X') residues, in order; returns mismatches + gap bases.  A run of
+// length 0 cannot occur (ksw_global merges operations); the reference would print "0X" for it, and so does this.
 int cigar4(const std::vector<uint32_t>& bam, const uint8_t* query, const uint8_t* rseq, Txt& sNM, Txt* sCig) {
-    int x = 0, y = 0, n_mm = 0, n_gap = 0;
-    for (size_t k = 0; k < bam.size(); ++k) {
-        int op = bam[k] & 0xf;
-        int len = (int)(bam[k] >> 4);
+    int x = 0, y = 0, edits = 0;
+    for (const uint32_t c : bam) {
+        const int op = (int)(c & 0xf), len = (int)(c >> 4);
         if (sCig) *sCig << len << "MIDSH"[op];
-        if (op == 0) {
-            int matchLen = 0, mmLen = 0;
-            for (int i = 0; i < len; i++) {
-                if (query[x + i] != rseq[y + i]) {
-                    ++n_mm; ++mmLen;
-                    if (matchLen) { sNM << matchLen << "="; matchLen = 0; }
-                } else {
-                    ++matchLen;
-                    if (mmLen) { sNM << mmLen << "X"; mmLen = 0; }
-                }
-            }
-            if (matchLen) sNM << matchLen << "=";
-            else sNM << mmLen << "X";
-            x += len; y += len;
-        } else {
+        if (op != 0) {
             sNM << len << "MIDSH"[op];
-            if (op == 1) { x += len; n_gap += len; }
-            else if (op == 2) { y += len; n_gap += len; }
+            if (op == 1) { x += len; edits += len; }
+            else if (op == 2) { y += len; edits += len; }
+            continue;
         }
+        if (len <= 0) sNM << 0 << 'X';
+        for (int at = 0; at < len;) {
+            const bool same = query[x + at] == rseq[y + at];
+            int run = 1;
+            while (at + run < len && (query[x + at + run] == rseq[y + at + run]) == same) ++run;
+            sNM << run << (same ? '=' : 'X');
+            if (!same) edits += run;
+            at += run;
+        }
+        x += len; y += len;
     }
-    return n_mm + n_gap;
+    return edits;
 }
 
 // recoverCIGAR3from4 src/mapper.cpp:54-77
@@ -438,66 +428,42 @@ void Mapper::cand_regions(const Read& read, std::vector<Lis>& lis, double errorP
 }
 
 // ------------------------------------------------------------------------------------------ chains
-// nextChain src/mapper.cpp:721-782
+// nextChain src/mapper.cpp:721-782: the greedy collinear chain around an anchor over the region's seeds (sorted by read
+// position).  One sweep per direction; `tip` is the seed the chain currently ends with on that side and `far` the coordinates
+// of its other end (the anchor's, which never move): a seed joins when it lies beyond the tip in read and text (up to 10
+// bases of overlap) and the skew between its two gaps is within errorPercent of the chain's span.  Same arithmetic as
+// mapcore::grow_chain (csrc/map_core.h), on the mapper's containers.
 static int next_chain(const std::vector<Match>& matches, std::list<size_t>& chain, size_t anchorPos, double errorPercent,
                       std::vector<bool>& used, size_t qLength, int& coverage) {
-    int curEditDist = 0;
-    coverage = 0;
-    coverage += (int)matches[anchorPos].len;
-    chain.clear();
-    chain.push_back(anchorPos);
-    const Match& firstSeed = matches[anchorPos];
-    int64_t refstrLB = firstSeed.ref;
-    int64_t queryLB = firstSeed.query;
-    int64_t refstrRB = refstrLB + firstSeed.len - 1;
-    int64_t queryRB = queryLB + firstSeed.len - 1;
-    int memsIndex = (int)anchorPos + 1;
-    while (memsIndex < (int)matches.size()) {
-        const Match& match = matches[memsIndex];
-        int64_t qDist = match.query - (queryRB + 1);
-        int64_t refDist = match.ref - (refstrRB + 1);
-        int64_t qDistLong = match.query + match.len - queryLB;
-        int64_t refDistLong = match.ref + match.len - refstrLB;
-        if (qDist >= MAX_OVERLAP && refDist >= MAX_OVERLAP &&
-            std::llabs(qDist - refDist) <= (int64_t)(errorPercent * std::max(qDistLong, refDistLong))) {
-            chain.push_back(memsIndex);
-            curEditDist += (int)std::max((int64_t)1, (int64_t)std::llabs(qDist - refDist));
-            refstrLB = match.ref;
-            refstrRB = match.ref + match.len - 1;
-            queryLB = match.query;
-            queryRB = match.query + match.len - 1;
-            used[memsIndex] = true;
-            coverage += std::min(qDist, refDist) < 0 ? (int)(matches[memsIndex].len + std::min(qDist, refDist)) : (int)matches[memsIndex].len;
+    const Match& anchor = matches[anchorPos];
+    chain.assign(1, anchorPos);
+    coverage = anchor.len;
+    int edits = 0;
+    for (const int step : {+1, -1}) {
+        Match tip = anchor;
+        for (int64_t k = (int64_t)anchorPos + step; k >= 0 && k < (int64_t)matches.size(); k += step) {
+            const Match& m = matches[(size_t)k];
+            int64_t qGap, rGap, qSpan, rSpan;
+            if (step > 0) {
+                qGap = (int64_t)m.query - ((int64_t)tip.query + tip.len); rGap = m.ref - (tip.ref + tip.len);
+                qSpan = (int64_t)m.query + m.len - tip.query;             rSpan = m.ref + m.len - tip.ref;
+            } else {
+                qGap = (int64_t)tip.query - ((int64_t)m.query + m.len);   rGap = tip.ref - (m.ref + m.len);
+                qSpan = (int64_t)tip.query + tip.len - m.query;           rSpan = tip.ref + tip.len - m.ref;
+            }
+            const int64_t skew = std::llabs(qGap - rGap);
+            if (qGap < MAX_OVERLAP || rGap < MAX_OVERLAP || skew > (int64_t)(errorPercent * std::max(qSpan, rSpan))) continue;
+            if (step > 0) chain.push_back((size_t)k); else chain.push_front((size_t)k);
+            used[(size_t)k] = true;
+            edits += (int)std::max<int64_t>(1, skew);
+            coverage += (int)(m.len + std::min<int64_t>(0, std::min(qGap, rGap)));
+            tip = m;
         }
-        memsIndex++;
+        // an uncovered read end costs one more edit
+        if (step > 0) edits += (int)(tip.query + tip.len) < (int)qLength ? 1 : 0;
+        else edits += tip.query > 0 ? 1 : 0;
     }
-    curEditDist += (int)(queryRB + 1) < (int)qLength ? 1 : 0;
-    memsIndex = (int)anchorPos - 1;
-    refstrLB = firstSeed.ref;
-    queryLB = firstSeed.query;
-    refstrRB = refstrLB + firstSeed.len - 1;
-    queryRB = queryLB + firstSeed.len - 1;
-    while (memsIndex >= 0) {
-        const Match& match = matches[memsIndex];
-        int64_t qDist = queryLB - (match.query + match.len);
-        int64_t refDist = refstrLB - (match.ref + match.len);
-        int64_t qDistLong = queryRB - (match.query) + 1;
-        int64_t refDistLong = refstrRB - (match.ref) + 1;
-        if (qDist >= MAX_OVERLAP && refDist >= MAX_OVERLAP &&
-            std::llabs(qDist - refDist) <= (int64_t)(errorPercent * std::max(qDistLong, refDistLong))) {
-            chain.push_front(memsIndex);
-            curEditDist += (int)std::max((int64_t)1, (int64_t)std::llabs(qDist - refDist));
-            refstrLB = match.ref;
-            refstrRB = match.ref + match.len - 1;
-            queryLB = match.query;
-            queryRB = match.query + match.len - 1;
-            used[memsIndex] = true;
-            coverage += std::min(qDist, refDist) < 0 ? (int)(matches[memsIndex].len + std::min(qDist, refDist)) : (int)matches[memsIndex].len;
-        }
-        memsIndex--;
-    }
-    curEditDist += queryLB > 0 ? 1 : 0;
-    return curEditDist;
+    return edits;
 }
 
 // leftExtension src/mapper.cpp:784-824

@@ -1850,28 +1850,39 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
     }
     struct Part { int64_t total_pref = 0; int max_w = 0; bool magic_ok = true; int err = 0; };
     auto pack_range = [&](int lo, int hi, Part& P) {
+        int c_plen = -1, c_min = -1, c_sq = -1;
+        int64_t c_np = 0;
+        int32_t c_nh = 0, c_kh = 0;
+        uint32_t c_m1 = 0, c_m2 = 0;
+        bool c_magic = true;
         for (int i = lo; i < hi; ++i) {
             SeedQ& s = hq[i];
             const size_t po = (size_t)s.poff;
             s.plen = q[i].plen; s.min_len = q[i].min_len; s.max_count = q[i].max_count; s.sparse_q = q[i].sparse_q;
-            const int64_t np = smem_like ? count_prefixes_smem(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q)
-                                                          : count_prefixes(ix->K, q[i].plen, q[i].min_len, q[i].sparse_q);
-            if (np < 0 || np > 0x3fffffff) { P.err = 1; return; }
-            s.npref = (int32_t)np;
-            {   // mirrors the device PrefixMap
-                const int64_t stp = (int64_t)q[i].sparse_q * ix->K;
-                const int64_t Lm = (int64_t)q[i].plen - (q[i].min_len - (stp - 1));
+            // the prefix enumeration depends on (plen, min_len, sparse_q) only: reads of one length share it (a dozen 64-bit
+            // divisions per strand were the larger half of the packing time)
+            if (q[i].plen != c_plen || q[i].min_len != c_min || q[i].sparse_q != c_sq) {
+                c_plen = q[i].plen; c_min = q[i].min_len; c_sq = q[i].sparse_q;
+                c_np = smem_like ? count_prefixes_smem(ix->K, c_plen, c_min, c_sq) : count_prefixes(ix->K, c_plen, c_min, c_sq);
+                // mirrors the device PrefixMap
+                const int64_t stp = (int64_t)c_sq * ix->K;
+                const int64_t Lm = (int64_t)c_plen - (c_min - (stp - 1));
                 const int64_t nh = Lm >= 0 ? Lm / stp + 1 : 0;
                 const int64_t kk = std::min<int64_t>(ix->K, Lm + 1), rr = Lm >= 0 ? Lm % stp : 0;
-                s.pm_nh = (int32_t)nh;
-                s.pm_kh = (int32_t)std::min<int64_t>(kk, rr + 1);
-                s.pm_m1 = s.pm_m2 = 0;
-                if (np >= 65536 || nh >= 65536) P.magic_ok = false;
-                if (np < 65536 && nh >= 2 && nh < 65536) {
-                    s.pm_m1 = (uint32_t)((0x100000000ull + (uint64_t)nh - 1) / (uint64_t)nh);
-                    if (nh >= 3) s.pm_m2 = (uint32_t)((0x100000000ull + (uint64_t)(nh - 1) - 1) / (uint64_t)(nh - 1));
+                c_nh = (int32_t)nh;
+                c_kh = (int32_t)std::min<int64_t>(kk, rr + 1);
+                c_m1 = c_m2 = 0;
+                c_magic = !(c_np >= 65536 || nh >= 65536);
+                if (c_np < 65536 && nh >= 2 && nh < 65536) {
+                    c_m1 = (uint32_t)((0x100000000ull + (uint64_t)nh - 1) / (uint64_t)nh);
+                    if (nh >= 3) c_m2 = (uint32_t)((0x100000000ull + (uint64_t)(nh - 1) - 1) / (uint64_t)(nh - 1));
                 }
             }
+            const int64_t np = c_np;
+            if (np < 0 || np > 0x3fffffff) { P.err = 1; return; }
+            s.npref = (int32_t)np;
+            s.pm_nh = c_nh; s.pm_kh = c_kh; s.pm_m1 = c_m1; s.pm_m2 = c_m2;
+            if (!c_magic) P.magic_ok = false;
             s.max_smem = q[i].max_smem_cont;
             s.soff = 0;
             P.max_w = std::max(P.max_w, (int)std::max<int64_t>(q[i].plen, np) + 2);

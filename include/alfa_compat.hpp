@@ -9,6 +9,10 @@
 //   alfa_compat::ksw_align / kswr_t / KSW_X*        == src/ksw.h:6-19,63 (the query-profile cache argument must be null)
 //   alfa_compat::sparseSA::SMAM / MEM / SMEM / SMEMP == src/sparseSA.h:274-283 (append to `matches`, never clear it)
 //   alfa_compat::match_t                            == src/sparseSA.h:103-110
+//   alfa_compat::dynProg (+ boundaries, dp_scores, dp_type, dp_output, outputType) == src/dp.h:29-74,76-137: the constructor
+//       and dpBandStatic / dpBandFull / dpBandScore / dpBasic with the reference's arguments; they mutate `boundaries` and fill
+//       `dp_output` as the reference does.  Where the reference calls exit(1) (a failed traceback, src/dp.cpp:402) or reads
+//       matrix cells it never wrote, the wrapper throws std::runtime_error instead.
 #pragma once
 #include <cstdlib>
 #include <cstring>
@@ -122,6 +126,82 @@ class sparseSA {
         alfa_free(m);
     }
     alfa_index* ix_ = nullptr;
+};
+
+// ---- dynProg (src/dp.h).  The reference's object owns the three DP matrices (one object per thread, src/dp.h:78); here the
+// matrices live on the device for the duration of a call, so the object only carries the scoring scheme.
+struct boundaries {
+    boundaries() : refB(0), refE(0), queryB(0), queryE(0) {}
+    boundaries(long refBegin, long refEnd, int queryBegin, int queryEnd) : refB(refBegin), refE(refEnd), queryB(queryBegin), queryE(queryEnd) {}
+    long refB, refE;
+    int queryB, queryE;
+};
+struct dp_scores {          // (the reference also holds the 127 x 127 matrix it derives from these four: updateScoreMatrixDna)
+    dp_scores() : match(0), mismatch(-1), openGap(0), extendGap(-1) {}
+    dp_scores(int m, int mm, int oG, int eG) : match(m), mismatch(mm), openGap(oG), extendGap(eG) {}
+    int match, mismatch, openGap, extendGap;
+    void updateScoreMatrixDna() {}
+};
+struct dp_type {
+    dp_type() : freeRefB(false), freeRefE(false), freeQueryB(false), freeQueryE(false), local(false) {}
+    dp_type(bool refB, bool refE, bool qB, bool qE, bool loc) : freeRefB(refB), freeRefE(refE), freeQueryB(qB), freeQueryE(qE), local(loc) {}
+    bool freeRefB, freeRefE, freeQueryB, freeQueryE, local;
+};
+struct dp_output {
+    dp_output() : editDist(0), dpScore(0) {}
+    int editDist, dpScore;
+    std::vector<char> cigarChars;
+    std::vector<int> cigarLengths;
+    void clear() { cigarChars.clear(); cigarLengths.clear(); editDist = dpScore = 0; }
+};
+enum outputType { DPSCORE, SCORE, ALIGNMENT, ERRORSTRING, ALL };
+
+struct dynProg {
+    dp_scores& scores;
+    const bool affine;
+    // `dimension` sized the reference's matrices; the device allocates per call
+    dynProg(int /*dimension*/, bool affine_, dp_scores& scoreFunction) : scores(scoreFunction), affine(affine_) {}
+    int dpBandStatic(const std::string& ref, const std::string& query, boundaries& offset, const dp_type& type, const outputType& oType,
+                     dp_output& output, int minbandSize, int maxbandSize, bool /*print*/ = false) {
+        return call(ALFA_DPBAND_STATIC, ref, query, offset, type, oType, output, minbandSize, maxbandSize);
+    }
+    int dpBandFull(const std::string& ref, const std::string& query, boundaries& offset, const dp_type& type, const outputType& oType,
+                   dp_output& output, int bandLeft, int bandRight, bool /*print*/ = false) {
+        return call(ALFA_DPBAND_FULL, ref, query, offset, type, oType, output, bandLeft, bandRight);
+    }
+    int dpBandScore(const std::string& ref, const std::string& query, boundaries& offset, const dp_type& type, const outputType& oType,
+                    dp_output& output, int bandLeft, int bandRight, bool /*print*/ = false) {
+        return call(ALFA_DPBAND_SCORE, ref, query, offset, type, oType, output, bandLeft, bandRight);
+    }
+    int dpBasic(const std::string& ref, const std::string& query, boundaries& offset, const dp_type& type, const outputType& oType, dp_output& output) {
+        return call(ALFA_DPBAND_BASIC, ref, query, offset, type, oType, output, 0, 0);
+    }
+
+   private:
+    int call(int variant, const std::string& ref, const std::string& query, boundaries& offset, const dp_type& type, const outputType& oType,
+             dp_output& output, int b1, int b2) {
+        alfa_dpband_scores sc = {scores.match, scores.mismatch, scores.openGap, scores.extendGap, affine ? 1 : 0};
+        alfa_dpband_task t;
+        std::memset(&t, 0, sizeof(t));
+        t.ref = ref.data(); t.ref_len = (int64_t)ref.size(); t.query = query.data(); t.query_len = (int64_t)query.size();
+        t.refB = offset.refB; t.refE = offset.refE; t.queryB = offset.queryB; t.queryE = offset.queryE;
+        t.freeRefB = type.freeRefB; t.freeRefE = type.freeRefE; t.freeQueryB = type.freeQueryB; t.freeQueryE = type.freeQueryE; t.local = type.local;
+        t.out_type = (int32_t)oType; t.band1 = b1; t.band2 = b2;
+        alfa_dpband_result r;
+        char* cc = nullptr;
+        int32_t* cl = nullptr;
+        must(alfa_dp_band_batch(variant, &sc, &t, 1, &r, &cc, &cl));
+        if (r.ret >= 2) {
+            alfa_free(cc); alfa_free(cl);
+            throw std::runtime_error(r.ret == 3 ? "alfa_compat::dynProg: the reference exits here (Error in dynamic programming, src/dp.cpp:402)"
+                                                : "alfa_compat::dynProg: the reference reads matrix cells it never wrote for these arguments");
+        }
+        output.dpScore = r.dpScore; output.editDist = r.editDist;
+        for (int32_t k = 0; k < r.n_cigar; ++k) { output.cigarChars.push_back(cc[r.cig_off + k]); output.cigarLengths.push_back(cl[r.cig_off + k]); }
+        offset.refB = (long)r.refB; offset.refE = (long)r.refE; offset.queryB = r.queryB; offset.queryE = r.queryE;
+        alfa_free(cc); alfa_free(cl);
+        return r.ret;
+    }
 };
 
 }  // namespace alfa_compat

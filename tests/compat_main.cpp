@@ -51,6 +51,35 @@ int main(int argc, char** argv) {
         alfa_compat::kswr_t a = alfa_compat::ksw_align((int)q.size(), q.data(), (int)t.size(), t.data(), 5, mat, -6, -1, xtra, 0);
         printf("A %zu %d %d %d %d %d %d %d\n", r, a.score, a.te, a.qe, a.score2, a.te2, a.tb, a.qb);
     }
+    // dynProg with the reference's call shapes (src/mapper.cpp:424-428 is its one call site): each read against the next one,
+    // a window of the target picked by the boundaries; ASCII strings
+    {
+        alfa_compat::dp_scores scores(1, -4, -6, -1);
+        scores.updateScoreMatrixDna();
+        alfa_compat::dynProg dp(2000, true, scores);
+        alfa_compat::dp_scores lin(2, -3, 0, -2);
+        alfa_compat::dynProg dpl(2000, false, lin);
+        for (size_t r = 0; r + 1 < reads.size(); ++r) {
+            const std::string &q = reads[r], &t = reads[r + 1];
+            if (q.size() < 20 || t.size() < 20) continue;
+            for (int v = 0; v < 4; ++v) {
+                alfa_compat::boundaries b(3, (long)t.size() - 4, 2, (int)q.size() - 3);
+                alfa_compat::dp_type type(v == 1, v == 1, false, v == 3, false);
+                alfa_compat::dp_output out;
+                int ret = -1;
+                try {
+                    const int d = (int)(t.size() > q.size() ? t.size() - q.size() : q.size() - t.size());
+                    if (v == 0) ret = dp.dpBandStatic(t, q, b, type, alfa_compat::ALL, out, 10, 10 + d + 50);
+                    else if (v == 1) ret = dp.dpBandFull(t, q, b, type, alfa_compat::ALL, out, 12 + d, 12 + d);
+                    else if (v == 2) ret = dpl.dpBandScore(t, q, b, type, alfa_compat::ALL, out, 15 + d, 15 + d);
+                    else ret = dpl.dpBasic(t, q, b, type, alfa_compat::ALL, out);
+                } catch (const std::exception& e) { ret = 9; }
+                printf("P %zu %d %d %d %d %ld %ld %d %d ", r, v, ret, out.dpScore, out.editDist, b.refB, b.refE, b.queryB, b.queryE);
+                for (size_t k = 0; k < out.cigarChars.size(); ++k) printf("%d%c", out.cigarLengths[k], out.cigarChars[k]);
+                printf("\n");
+            }
+        }
+    }
     alfa_host_index_free(h);
     return 0;
 }

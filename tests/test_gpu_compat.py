@@ -34,6 +34,7 @@ def test_reference_signatures_batch_of_one(gpu):
     nt4 = np.full(256, 4, np.uint8)
     for i, c in enumerate(b"acgt"):
         nt4[c] = i
+    n_dynprog = [0]
     for ln in lines:
         f = ln.split()
         if not f:
@@ -46,6 +47,23 @@ def test_reference_signatures_batch_of_one(gpu):
                 exp += [(int(x["ref"]), int(x["query"]), int(x["len"])) for x in m]
             got = [tuple(int(v) for v in t.split(",")) for t in f[3:]]
             assert int(f[2]) == len(exp) and got == exp, r
+        elif f[0] == "P":
+            # alfa_compat::dynProg: the four methods against the dynProg oracle (oracle/dp_oracle.cpp) on the same arguments
+            v = int(f[2])
+            q, t = reads[r], reads[r + 1]
+            d = abs(len(t) - len(q))
+            spec = {"ref": t, "query": q, "refB": 3, "refE": len(t) - 4, "queryB": 2, "queryE": len(q) - 3, "out_type": 4,
+                    "flags": (v == 1, v == 1, False, v == 3, False)}
+            spec["band1"], spec["band2"] = [(10, 10 + d + 50), (12 + d, 12 + d), (15 + d, 15 + d), (0, 0)][v]
+            sc = ffi.DpbandScores(1, -4, -6, -1, 1) if v < 2 else ffi.DpbandScores(2, -3, 0, -2, 0)
+            exp = O.orc_dp_band_batch(v, sc, ffi.make_dpband_tasks([spec]))[0]
+            got_ret = int(f[3])
+            if exp[0] >= 2:
+                assert got_ret == 9, (r, v, exp)          # the wrapper throws where the reference exits / reads unwritten cells
+            else:
+                cig = f[10] if len(f) > 10 else ""
+                assert (got_ret, int(f[4]), int(f[5]), int(f[6]), int(f[7]), int(f[8]), int(f[9]), cig) == tuple(exp), (r, v, exp, f)
+            n_dynprog[0] += 1
         elif f[0] == "A":
             q, t = nt4[np.frombuffer(reads[r], np.uint8)], nt4[np.frombuffer(reads[r + 1], np.uint8)]
             pa = ffi.default_params()
@@ -62,3 +80,4 @@ def test_reference_signatures_batch_of_one(gpu):
             sg, cig, nc, off = O.orc_ksw_global_batch(P, tk0)
             exp = [int(x) for x in e] + [sn, int(sg[0]), int(nc[0])] + [int(c) for c in cig[:nc[0]]]
             assert [int(v) for v in f[2:]] == exp, r
+    assert n_dynprog[0] >= 30

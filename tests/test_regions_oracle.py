@@ -103,3 +103,52 @@ def test_python_restatement_on_the_synthetic_set():
         n += 1
         nreg += len(regs)
     assert n > 2000 and nreg > 2000, (n, nreg)
+
+
+# ---- the REFERENCE's regions: oracle/_ref/alfalfa_reglog is the reference executable compiled in place with a logger in front
+# of calculateCandRegions' final sort (oracle/ref_region_logger.h), so the regions identifyAndFilter + coveredBases build for
+# every read -- members, bounds, scores, creation order -- can be compared with the host mapper's (logged with ALFA_REGION_LOG),
+# to which the Python restatement above is pinned with their input seeds.  Reference == host mapper == regions_oracle.py.
+REF_REGLOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "alfalfa_reglog")
+
+
+def _ref_records(path):
+    lines = open(path).read().split("\n")
+    i = 0
+    while i < len(lines) and lines[i]:
+        tag, nreg = lines[i].split()
+        assert tag == "R"
+        i += 1
+        regs = []
+        for _ in range(int(nreg)):
+            g = lines[i].split()
+            assert g[0] == "G"
+            i += 1
+            mem = [tuple(int(x) for x in lines[i + j].split()) for j in range(int(g[5]))]
+            i += int(g[5])
+            regs.append((int(g[1]), int(g[2]), int(g[3]), int(g[4]), tuple(mem)))
+        yield tuple(regs)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_REGLOG), reason="compiled reference with the region logger not in the tree")
+@pytest.mark.parametrize("name,extra", [("454_s12", []), ("454_s1", []), ("pe_s12", []), ("454_s12_e12", []),
+                                        ("454_s12", ["-m", "3", "--max-mems", "2", "--min-mem-length", "30"])])
+def test_reference_regions_equal_host_mapper_regions(name, extra):
+    from collections import Counter
+    d = M.workdir()
+    K, args = M.CONFIGS[name]
+    logs = {}
+    for tag, exe, var in (("ref", REF_REGLOG, "ALFA_REF_REGION_LOG"), ("host", M.CPU_EXE, "ALFA_REGION_LOG")):
+        log = os.path.join(d, "reglog_%s_%s_%d.log" % (tag, name, len(extra)))
+        pre = os.path.join(d, "idx_%s_%d" % (os.path.basename(M.CPU_EXE), K))
+        if not os.path.exists(pre + ".aux"):
+            subprocess.run([M.CPU_EXE, "index", "-r", "reference.fasta", "-p", pre, "-s", str(K)], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL)
+        p = subprocess.run([exe, "align", "-i", pre, "-o", os.path.join(d, "reglog_%s.sam" % tag), "-t", "1"] + args + extra, cwd=d,
+                           env=dict(os.environ, **{var: log}), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-1000:]
+        logs[tag] = log
+    ref = Counter(_ref_records(logs["ref"]))
+    host = Counter(tuple((fw, rb, re_, sc, tuple(mem)) for fw, rb, re_, sc, mem in regs) for _q, _e, _f, _r, regs in _records(logs["host"]))
+    assert sum(ref.values()) >= 100 and sum(len(r) for r in ref.elements()) >= 100
+    assert ref == host

@@ -1,4 +1,5 @@
-"""alfa_ksw_global_noalloc (the entry point that allocates nothing) vs alfa_ksw_global_batch, through the C ABI, on the GPU.
+"""alfa_ksw_global_noalloc (the entry point that allocates nothing) vs alfa_ksw_global_batch AND vs the oracle (a regression that
+hit both entry points alike would otherwise pass), through the C ABI, on the GPU.
 
 Two calls in a row on the same device array, the second with a smaller input; bit-exact scores and CIGARs.
 The caller's device buffers come from the HIP runtime through ctypes (tests/hip_rt.py).
@@ -7,6 +8,7 @@ import numpy as np
 import pytest
 
 from alfalfa_amd import ffi
+import oracle_ffi as O
 import dpgen
 import hip_rt
 
@@ -41,9 +43,14 @@ def _check(P, pairs, ws):
     s0, c0, n0, o0 = ffi.ksw_global_batch(P, tasks)
     assert np.array_equal(score, s0)
     assert np.array_equal(ncig, n0)
+    so, co, no, oo = O.orc_ksw_global_batch(P, tasks)
+    assert np.array_equal(score, so)
     for i in range(len(pairs)):
         if n0[i] > 0:
             assert np.array_equal(cig[i, cig_stride - n0[i]:], c0[o0[i]:o0[i] + n0[i]]), i
+            assert ncig[i] == no[i] and np.array_equal(cig[i, cig_stride - n0[i]:], co[oo[i]:oo[i] + no[i]]), i
+        else:
+            assert len(pairs[i][1]) > len(pairs[i][0]) + ws[i]        # only where the reference indexes outside its matrix
     return int((n0 > 0).sum())
 
 
