@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
                     const int d = (int)(t.size() > q.size() ? t.size() - q.size() : q.size() - t.size());
                     if (v == 0) ret = dp.dpBandStatic(t, q, b, type, alfa_compat::ALL, out, 10, 10 + d + 50);
                     else if (v == 1) ret = dp.dpBandFull(t, q, b, type, alfa_compat::ALL, out, 12 + d, 12 + d);
-                    else if (v == 2) ret = dpl.dpBandScore(t, q, b, type, alfa_compat::ALL, out, 15 + d, 15 + d);
+                    else if (v == 2) ret = dp.dpBandScore(t, q, b, type, alfa_compat::ALL, out, 15 + d, 15 + d);
                     else ret = dpl.dpBasic(t, q, b, type, alfa_compat::ALL, out);
                 } catch (const std::exception& e) { ret = 9; }
                 printf("P %zu %d %d %d %d %ld %ld %d %d ", r, v, ret, out.dpScore, out.editDist, b.refB, b.refE, b.queryB, b.queryE);

@@ -55,7 +55,7 @@ def test_reference_signatures_batch_of_one(gpu):
             spec = {"ref": t, "query": q, "refB": 3, "refE": len(t) - 4, "queryB": 2, "queryE": len(q) - 3, "out_type": 4,
                     "flags": (v == 1, v == 1, False, v == 3, False)}
             spec["band1"], spec["band2"] = [(10, 10 + d + 50), (12 + d, 12 + d), (15 + d, 15 + d), (0, 0)][v]
-            sc = ffi.DpbandScores(1, -4, -6, -1, 1) if v < 2 else ffi.DpbandScores(2, -3, 0, -2, 0)
+            sc = ffi.DpbandScores(1, -4, -6, -1, 1) if v < 3 else ffi.DpbandScores(2, -3, 0, -2, 0)
             exp = O.orc_dp_band_batch(v, sc, ffi.make_dpband_tasks([spec]))[0]
             got_ret = int(f[3])
             if exp[0] >= 2:
