@@ -102,9 +102,11 @@ __device__ __forceinline__ void chain_priority(int rows) {
 // PACK (ksw_extend): the row maximum and its last column come out of one reduction over (H << 8 | diagonal); the caller
 // passes true only when the task's scores stay below 2^22 (every H <= h0 + qlen * maxs: wave_task_packs)
 // results are wave-uniform and come back through `eo` (ksw_extend) / `score_out` (ksw_nw, ksw_global)
-template <int MODE, int C, bool PACK = false>
+// ZCOMPACT (ksw_global): rows of direction bytes are `zstride` bytes apart (a multiple of C, > 2w + 1) instead of 64 * C, and only
+// the lanes inside a row store -- a short task's matrix then fits a few KB of LDS (map_kernels.hip)
+template <int MODE, int C, bool PACK = false, bool ZCOMPACT = false>
 __device__ __forceinline__ void wave_task_run(const DevTask T, const uint8_t* __restrict__ seq, const DevParams* __restrict__ prm,
-                                              uint8_t* __restrict__ zbuf, ExtOut& eo, int& score_out) {
+                                              uint8_t* __restrict__ zbuf, ExtOut& eo, int& score_out, int zstride = 64 * C) {
     const int lane = lane_id();
     // the task is the same for all 64 lanes: its fields in scalar registers make the row loop and its bounds wave-uniform
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
@@ -250,10 +252,12 @@ __device__ __forceinline__ void wave_task_run(const DevTask T, const uint8_t* __
             }
         }
         if (MODE == MODE_GLOBAL) {
-            uint8_t* zr = zrow0 + (int64_t)i * ROWB + lane * C;
-            if (C == 4) *(uint32_t*)zr = zpack;
-            else if (C == 2) *(uint16_t*)zr = (uint16_t)zpack;
-            else *zr = (uint8_t)zpack;
+            uint8_t* zr = zrow0 + (int64_t)i * (ZCOMPACT ? zstride : ROWB) + lane * C;
+            if (!ZCOMPACT || lane * C < zstride) {
+                if (C == 4) *(uint32_t*)zr = zpack;
+                else if (C == 2) *(uint16_t*)zr = (uint16_t)zpack;
+                else *zr = (uint8_t)zpack;
+            }
         }
 
         if (MODE == MODE_EXTEND) {

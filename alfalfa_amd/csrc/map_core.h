@@ -28,9 +28,9 @@
 namespace alfa {
 namespace mapcore {
 
-constexpr int MEMBER_CAP = 192;     // seeds of one candidate region
+constexpr int MEMBER_CAP = 160;     // seeds of one candidate region
 constexpr int REGION_CAP2 = 128;    // candidate regions of a read, both strands
-constexpr int TREE_CAP = 128;       // distinct read positions in hasUnique's interval tree, per strand
+constexpr int TREE_CAP = 96;        // distinct read positions in hasUnique's interval tree, per strand
 constexpr int BOUND_CAP = 24;       // chains tried in one region (alnBounds)
 constexpr int ALN_CAP = 8;          // alignments reported per read
 constexpr int CHAINOUT_CAP = 96;    // seeds of all reported chains of a read

@@ -35,6 +35,7 @@ __device__ __forceinline__ uint8_t nt4_of(uint8_t c) {
 }
 
 constexpr int SEQ_OFF = 16;        // wave_task's 8-byte windows may start a few bytes in front of a sequence
+constexpr int ZTILE = 4096;        // direction bytes of a ksw_global call that fit here stay in LDS, rows packed to the band's width
 
 struct DevEnv {
     const MapKernelArgs& A;
@@ -42,6 +43,7 @@ struct DevEnv {
     const uint8_t* Pf;
     const uint8_t* Pr;
     uint8_t* scr;
+    uint8_t* ztile;
     const DevParams* prm;
     const alfa_region* regF; const alfa_region* regR;
     const alfa_match* memF; const alfa_match* memR;
@@ -142,14 +144,20 @@ struct DevEnv {
         if (w > lim) w = lim;
         if (w < 0 || 2 * w + 1 > 256 || tLen > qLen + w) return -1;      // (tlen > qlen + w: the reference indexes outside its matrix)
         const int C4 = 2 * w + 1 > 128;
-        const int rowb = C4 ? 256 : 128;
-        if ((int64_t)tLen * rowb > A.zstride) return -1;
+        // short pieces (the common case on short reads: a gap or an overhang of a few dozen residues) keep their direction
+        // bytes in LDS, rows packed to the band's width -- the walk is a chain of dependent reads, 60 of them through HBM were
+        // half of the kernel's time; longer ones go to the read's slot of A.zscratch at the batch kernels' row stride
+        const int wpad = (2 * w + 1 + 4) & ~3;               // > 2w + 1, a multiple of 4
+        const bool in_lds = !C4 && tLen * wpad <= ZTILE;
+        const int rowb = in_lds ? wpad : (C4 ? 256 : 128);
+        if (!in_lds && (int64_t)tLen * rowb > A.zstride) return -1;
         if (!stage(fw, false, qFrom, qLen, tFrom, tLen)) return -1;
-        uint8_t* z = A.zscratch + (int64_t)r * A.zstride;
+        uint8_t* z = in_lds ? ztile : A.zscratch + (int64_t)r * A.zstride;
         const DevTask T = task(qLen, tLen, w, 0);
         ExtOut eo;
         int s = 0;
-        if (!C4) wave_task_run<MODE_GLOBAL, 2>(T, scr, prm, z, eo, s);
+        if (in_lds) wave_task_run<MODE_GLOBAL, 2, false, true>(T, scr, prm, z, eo, s, wpad);
+        else if (!C4) wave_task_run<MODE_GLOBAL, 2>(T, scr, prm, z, eo, s);
         else wave_task_run<MODE_GLOBAL, 4>(T, scr, prm, z, eo, s);
         __threadfence_block();
         __syncthreads();
@@ -186,8 +194,9 @@ struct DevEnv {
     }
 };
 
-__global__ __launch_bounds__(64) void map_kernel(const MapKernelArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void map_kernel(const MapKernelArgs A) {
     __shared__ Work W;
+    __shared__ __align__(16) uint8_t ztile[ZTILE];
     const int r = blockIdx.x, ln = threadIdx.x;
     if (r >= A.n) return;
     const int sf = 2 * r, sr = 2 * r + 1;
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(64) void map_kernel(const MapKernelArgs A) {
     if (A.rstatus[sf] | A.rstatus[sr]) status = mapcore::NEED_CALLER;           // regions_kernel handed a strand back
     else if (be == bf) status = A.opt.rescue ? mapcore::NEED_CALLER : mapcore::DONE;      // no seed on either strand: the seed rescue rounds (src/mapper.cpp:542-555) stay with the caller
     else {
-        DevEnv env{A, ln, r, A.reads + A.read_off[sf], A.reads + A.read_off[sr], A.scratch + (int64_t)r * A.scratch_stride,
+        DevEnv env{A, ln, r, A.reads + A.read_off[sf], A.reads + A.read_off[sr], A.scratch + (int64_t)r * A.scratch_stride, ztile,
                    (const DevParams*)A.dp_params, A.reg + bf, A.reg + br, A.members + 2 * bf + 8 * (int64_t)sf,
                    A.members + 2 * br + 8 * (int64_t)sr, A.nreg[sf], A.nreg[sr]};
         const int nreg = env.nF + env.nR;

@@ -155,7 +155,7 @@ int  alfa_seed_regions_batch(alfa_index*, int mem_type, const alfa_seed_query* q
  *                   (*seeds)[seed_off[i] + a.chain_first .. + a.chain_count).  No alignments = the reference finds none
  *                   without re-seeding either (possible only with rescue == 0, or when the read has seeds but no region).
  *   status[i] == 1: the caller maps read i itself through the entry points above (what the reference does next is the
- *                   re-seeding rescue, :542-555 or :1290-1300; or a capacity of the kernel was exceeded: more than 192 seeds
+ *                   re-seeding rescue, :542-555 or :1290-1300; or a capacity of the kernel was exceeded: more than 160 seeds
  *                   in a region, 128 regions, 8 alignments or 24 chains per region, a band beyond 256 diagonals; or a strand
  *                   alfa_seed_regions_batch would hand back).  Results are then empty for that read.
  * The float arithmetic that depends only on the read length stays on the host and arrives per read (alfa_map_read), so
