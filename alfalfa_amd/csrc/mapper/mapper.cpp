@@ -12,6 +12,7 @@
 #include <deque>
 #include <list>
 #include <mutex>
+#include <condition_variable>
 #include <map>
 #include <charconv>
 #include <type_traits>
@@ -760,7 +761,7 @@ struct CoreEnv {
 }  // namespace
 
 std::atomic<long> g_core_done{0}, g_core_fallback{0};
-std::atomic<long> g_map_us[4];      // whole-read device calls, microseconds over all workers: describe, the call, adopt; [3] counts the
+std::atomic<long> g_map_us[5];      // whole-read device calls, microseconds over all workers: describe, the call, adopt; [3] counts the
                                     // alignments whose CIGAR came with them
 
 mapcore::Options core_options(const AlignOpt& o) {
@@ -1015,81 +1016,248 @@ bool Mapper::device_map_usable() const {
     return opt_.deviceMap && hot_.ops().map_reads_batch && !opt_.noFW && !opt_.noRC && !opt_.coreTrials && !opt_.deviceRegions;
 }
 
-void Mapper::map_batch(Read* const* reads, int n, std::vector<uint8_t>& done) {
-    done.assign((size_t)n, 0);
-    if (n <= 0) return;
-    const int K = (int)idx_.K();
-    alfa_map_options mo;
+// An optional cap on the whole-read device calls of one GPU that are in flight at a time (ALFA_MAP_LANES=n; default 0 = no cap).
+// A call is a chain of a dozen launches, copies and three host waits; when all workers call at once their chains interleave on
+// the GPU's few hardware queues and every call waits behind everybody else's kernels.  What cured that was taking the barrier
+// between batches out of the pipeline (mapper_cli.cpp: the workers drift apart); with that in place a cap only adds waiting
+// (2 000 000 short reads, 16 workers: map phase 0.63 s uncapped, 0.62-0.65 s with 2-8 lanes, 0.95 s with 1), so it stays off.
+namespace {
+struct Lanes {
+    std::mutex mu;
+    std::condition_variable cv;
+    int free_ = 0;
+    bool unlimited = false;
+};
+Lanes& lanes_of(const void* device_index) {
+    static std::mutex mu;
+    static std::map<const void*, std::unique_ptr<Lanes>> all;
+    std::lock_guard<std::mutex> g(mu);
+    std::unique_ptr<Lanes>& l = all[device_index];
+    if (!l) {
+        l.reset(new Lanes);
+        const char* e = getenv("ALFA_MAP_LANES");
+        const int n = e ? atoi(e) : 0;
+        l->free_ = n;
+        l->unlimited = n <= 0;
+    }
+    return *l;
+}
+struct LaneHold {
+    Lanes& l;
+    explicit LaneHold(Lanes& x) : l(x) {
+        if (l.unlimited) return;
+        std::unique_lock<std::mutex> g(l.mu);
+        l.cv.wait(g, [&] { return l.free_ > 0; });
+        --l.free_;
+    }
+    ~LaneHold() {
+        if (l.unlimited) return;
+        { std::lock_guard<std::mutex> g(l.mu); ++l.free_; }
+        l.cv.notify_one();
+    }
+};
+}  // namespace
+
+void Mapper::map_options(alfa_map_options& mo) const {
     memset(&mo, 0, sizeof(mo));
     mo.match = opt_.match; mo.mismatch = opt_.mismatch; mo.open_gap = opt_.openGap; mo.extend_gap = opt_.extendGap;
     mo.global = opt_.global ? 1 : 0; mo.fixed_band = opt_.fixedBandSize; mo.max_trial = opt_.maxTrial; mo.max_trial_best = opt_.maxTrialBest ? 1 : 0;
     mo.max_aln_count = opt_.maxAlnCount; mo.rescue = opt_.rescue ? 1 : 0;
     mo.mem_type = opt_.memType; mo.max_seed_candidates = opt_.maxSeedCandidates; mo.max_smem_start = opt_.maxSmemMemStart;
     mo.max_region_mems = opt_.maxRegionMems; mo.min_mem_reg_length = opt_.minMemRegLength; mo.error_percent = opt_.errorPercent;
-    std::vector<alfa_map_read> rd((size_t)n);
-    const auto tm0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < n; ++i) {
-        const Read& r = *reads[i];
-        const int Plength = (int)r.sequence.length();
-        const mapcore::ReadParams R = core_read_params(opt_, Plength);
-        // min_len: calculateCandRegions src/mapper.cpp:1225-1231; sparseSkip: calculateSeedsBothStrands :533-536
-        int min_len = opt_.minMemLength;
-        if (!opt_.fixedMinLength && Plength >= 1000) min_len += (20 * ((int)(Plength / 500))) / ((int)100 * opt_.errorPercent);
-        if (opt_.fixedMinLength && Plength / R.editDist > min_len) min_len = Plength / R.editDist;
-        int sparseSkip = K >= 4 ? std::max((min_len - 10) / K, 1) : std::max((min_len - 12) / K, 1);
-        if (opt_.noSparseQ) sparseSkip = 1;
-        alfa_map_read& x = rd[(size_t)i];
-        x.P = r.sequence.data(); x.Prc = r.rcSequence.data(); x.plen = Plength;
-        x.min_len = min_len; x.sparse_q = sparseSkip;
-        x.edit_dist = R.editDist; x.min_score = R.minScore; x.min_coverage = R.minCoverage; x.min_score2 = R.minScore2; x.min_coverage2 = R.minCoverage2;
-    }
-    std::vector<int32_t> st((size_t)n);
-    std::vector<int64_t> aoff((size_t)n + 1), soff((size_t)n + 1), ooff((size_t)n + 1);
-    alfa_map_alignment* al = nullptr;
-    alfa_match* sd = nullptr;
-    alfa_map_cigar_op* op = nullptr;
     mo.cigar_alignments = opt_.fullDP ? 0 : opt_.alignmentCount;
-    const auto t0 = std::chrono::steady_clock::now();
-    const int rc = hot_.ops().map_reads_batch(hot_.ops().index, &mo, &hot_.dp_params(), rd.data(), n, st.data(), aoff.data(), &al, soff.data(), &sd, ooff.data(), &op);
+}
+
+void Mapper::describe(const char* P, const char* Prc, int Plength, alfa_map_read& x) const {
+    const int K = (int)idx_.K();
+    const mapcore::ReadParams R = core_read_params(opt_, Plength);
+    // min_len: calculateCandRegions src/mapper.cpp:1225-1231; sparseSkip: calculateSeedsBothStrands :533-536
+    int min_len = opt_.minMemLength;
+    if (!opt_.fixedMinLength && Plength >= 1000) min_len += (20 * ((int)(Plength / 500))) / ((int)100 * opt_.errorPercent);
+    if (opt_.fixedMinLength && Plength / R.editDist > min_len) min_len = Plength / R.editDist;
+    int sparseSkip = K >= 4 ? std::max((min_len - 10) / K, 1) : std::max((min_len - 12) / K, 1);
+    if (opt_.noSparseQ) sparseSkip = 1;
+    x.P = P; x.Prc = Prc; x.plen = Plength;
+    x.min_len = min_len; x.sparse_q = sparseSkip;
+    x.edit_dist = R.editDist; x.min_score = R.minScore; x.min_coverage = R.minCoverage; x.min_score2 = R.minScore2; x.min_coverage2 = R.minCoverage2;
+}
+
+void Mapper::map_call(const alfa_map_options& mo, int n, MapCallResult& R) {
+    R.st.assign((size_t)n, 0);
+    R.aoff.assign((size_t)n + 1, 0); R.soff.assign((size_t)n + 1, 0); R.ooff.assign((size_t)n + 1, 0);
+    R.free_fn = hot_.ops().free_fn;
+    static thread_local Lanes* lanes = nullptr;
+    if (!lanes) lanes = &lanes_of(hot_.ops().index);
+    const auto tw0 = std::chrono::steady_clock::now();
+    int rc;
+    std::chrono::steady_clock::time_point t0;
+    {
+        LaneHold hold(*lanes);
+        t0 = std::chrono::steady_clock::now();
+        rc = hot_.ops().map_reads_batch(hot_.ops().index, &mo, &hot_.dp_params(), rd_.data(), n, R.st.data(), R.aoff.data(), &R.al, R.soff.data(), &R.sd,
+                                        R.ooff.data(), &R.op);
+    }
     const auto t1 = std::chrono::steady_clock::now();
+    g_map_us[4] += (long)std::chrono::duration<double, std::micro>(t0 - tw0).count();
     hot_.add_hot_seconds(std::chrono::duration<double>(t1 - t0).count());
-    g_map_us[0] += (long)std::chrono::duration<double, std::micro>(t0 - tm0).count();
     g_map_us[1] += (long)std::chrono::duration<double, std::micro>(t1 - t0).count();
     if (rc) {
         fprintf(stderr, "ERROR: alfa_map_reads_batch failed (%d): %s\n", rc, hot_.ops().last_error ? hot_.ops().last_error() : "");
         exit(1);
     }
     long nd = 0;
-    for (int i = 0; i < n; ++i) {
-        if (st[(size_t)i] != 0) continue;
-        Read& r = *reads[i];
-        for (int64_t k = aoff[(size_t)i]; k < aoff[(size_t)i + 1]; ++k) {
-            const alfa_map_alignment& o = al[k];
-            Alignment* a = new Alignment();
-            a->refB = o.ref_begin; a->refE = o.ref_end; a->qB = o.q_begin; a->qE = o.q_end; a->alignmentScore = o.score;
-            if (!o.forward) a->flag |= 1u << 4;
-            a->refLength = (int)(o.ref_end - o.ref_begin + 1);
-            static_assert(sizeof(Match) == sizeof(alfa_match), "Match == alfa_match");
-            const Match* s0 = (const Match*)(sd + soff[(size_t)i] + o.chain_first);
-            a->chain.assign(s0, s0 + o.chain_count);
-            if (o.op_count >= 0) {
-                static_assert(sizeof(mapcore::CigOp) == sizeof(alfa_map_cigar_op), "CigOp == alfa_map_cigar_op");
-                const mapcore::CigOp* p0 = (const mapcore::CigOp*)(op + ooff[(size_t)i] + o.op_first);
-                a->ops.assign(p0, p0 + o.op_count);
-                a->haveOps = true;
-                a->opsEdit = o.edit_dist;
-            }
-            r.alignments.push_back(a);
-        }
-        done[(size_t)i] = 1;
-        ++nd;
-    }
+    for (int i = 0; i < n; ++i) nd += R.st[(size_t)i] == 0;
     g_core_done += nd;
     g_core_fallback += n - nd;
-    hot_.ops().free_fn(al);
-    hot_.ops().free_fn(sd);
-    hot_.ops().free_fn(op);
+}
+
+// the call's alignments of read i as alignment_t objects, as unpairedMatch would have left them
+void Mapper::adopt(Read& r, const MapCallResult& R, int i) {
+    for (int64_t k = R.aoff[(size_t)i]; k < R.aoff[(size_t)i + 1]; ++k) {
+        const alfa_map_alignment& o = R.al[k];
+        Alignment* a = new Alignment();
+        a->refB = o.ref_begin; a->refE = o.ref_end; a->qB = o.q_begin; a->qE = o.q_end; a->alignmentScore = o.score;
+        if (!o.forward) a->flag |= 1u << 4;
+        a->refLength = (int)(o.ref_end - o.ref_begin + 1);
+        static_assert(sizeof(Match) == sizeof(alfa_match), "Match == alfa_match");
+        const Match* s0 = (const Match*)(R.sd + R.soff[(size_t)i] + o.chain_first);
+        a->chain.assign(s0, s0 + o.chain_count);
+        if (o.op_count >= 0) {
+            static_assert(sizeof(mapcore::CigOp) == sizeof(alfa_map_cigar_op), "CigOp == alfa_map_cigar_op");
+            const mapcore::CigOp* p0 = (const mapcore::CigOp*)(R.op + R.ooff[(size_t)i] + o.op_first);
+            a->ops.assign(p0, p0 + o.op_count);
+            a->haveOps = true;
+            a->opsEdit = o.edit_dist;
+        }
+        r.alignments.push_back(a);
+    }
+}
+
+void Mapper::map_batch(Read* const* reads, int n, std::vector<uint8_t>& done) {
+    done.assign((size_t)n, 0);
+    if (n <= 0) return;
+    alfa_map_options mo;
+    map_options(mo);
+    const auto tm0 = std::chrono::steady_clock::now();
+    rd_.resize((size_t)n);
+    for (int i = 0; i < n; ++i) describe(reads[i]->sequence.data(), reads[i]->rcSequence.data(), (int)reads[i]->sequence.length(), rd_[(size_t)i]);
+    g_map_us[0] += (long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tm0).count();
+    MapCallResult R;
+    map_call(mo, n, R);
+    const auto t1 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) {
+        if (R.st[(size_t)i] != 0) continue;
+        adopt(*reads[i], R, i);
+        done[(size_t)i] = 1;
+    }
     g_map_us[2] += (long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+}
+
+void Mapper::map_raw(const RawRead* raw, int n, MapCallResult& R) {
+    if (n <= 0) { R.st.clear(); R.aoff.assign(1, 0); R.soff.assign(1, 0); R.ooff.assign(1, 0); return; }
+    alfa_map_options mo;
+    map_options(mo);
+    const auto tm0 = std::chrono::steady_clock::now();
+    strandOff_.resize((size_t)n);
+    rawLen_.resize((size_t)n);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) { strandOff_[(size_t)i] = total; rawLen_[(size_t)i] = raw[i].len; total += 2 * (size_t)raw[i].len; }
+    if (strands_.size() < total) strands_.resize(total);
+    rd_.resize((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const int len = raw[i].len;
+        char* fw = &strands_[strandOff_[(size_t)i]];
+        char* rc = fw + len;
+        const unsigned char* s = (const unsigned char*)raw[i].seq;
+        for (int k = 0; k < len; ++k) {      // tolower in the "C" locale (the reader, src/fasta.cpp:147), then read_t::init's reverse complement
+            const unsigned char c = (unsigned char)(s[k] + ((unsigned char)(s[k] - 'A') < 26u ? 32 : 0));
+            fw[k] = (char)c;
+            rc[len - 1 - k] = RC.t[c];
+        }
+        describe(fw, rc, len, rd_[(size_t)i]);
+    }
+    g_map_us[0] += (long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tm0).count();
+    map_call(mo, n, R);
+}
+
+// a read the device finished, with no alignment or with exactly one that brought its CIGAR along, and one alignment to print
+bool Mapper::direct_ok(const MapCallResult& R, int i) const {
+    if (R.st[(size_t)i] != 0 || opt_.fullDP || opt_.alignmentCount < 1) return false;
+    const int64_t na = R.aoff[(size_t)i + 1] - R.aoff[(size_t)i];
+    return na == 0 || (na == 1 && R.al[R.aoff[(size_t)i]].op_count >= 0);
+}
+
+namespace {
+inline char* put_int(char* p, long v) {
+    auto r = std::to_chars(p, p + 24, v);
+    return r.ptr;
+}
+}  // namespace
+
+void Mapper::render_direct(const RawRead& rr, int i, const MapCallResult& R, std::string& out, long* mappedPrinted) {
+    const int len = rr.len;
+    const size_t at = out.size();
+    if (R.aoff[(size_t)i + 1] == R.aoff[(size_t)i]) {          // read_t::emptyAlingment src/mapper.h:170-179, unpaired
+        out.resize(at + (size_t)rr.nameLen + 2 * (size_t)len + 32);
+        char* p = &out[at];
+        memcpy(p, rr.name, (size_t)rr.nameLen); p += rr.nameLen;
+        static const char mid[] = "\t4\t*\t0\t0\t*\t*\t0\t0\t";
+        memcpy(p, mid, sizeof(mid) - 1); p += sizeof(mid) - 1;
+        memcpy(p, strand(i, false), (size_t)len); p += len;
+        *p++ = '\t';
+        memcpy(p, rr.qual, (size_t)len); p += len;
+        *p++ = '\n';
+        out.resize((size_t)(p - out.data()));
+        return;
+    }
+    const alfa_map_alignment& a = R.al[R.aoff[(size_t)i]];
+    const alfa_map_cigar_op* ops = R.op + R.ooff[(size_t)i] + a.op_first;
+    const int nops = a.op_count;
+    const bool rc = !a.forward;
+    // setLocalPos src/mapper.h:104-112
+    int64_t seq, pos;
+    idx_.from_set(a.ref_begin + 1, seq, pos);
+    const char* rname = idx_.descr(seq);
+    const size_t rl = strlen(rname);
+    // MAPQ of a single alignment, read_t::postprocess src/mapper.cpp:343-357
+    const int secBest = opt_.mismatch * len;
+    int mapq = a.score == secBest ? 0 : MAX_MAPQ;
+    out.resize(at + (size_t)rr.nameLen + rl + 2 * (size_t)len + 24 * (size_t)nops + 160);
+    char* p = &out[at];
+    memcpy(p, rr.name, (size_t)rr.nameLen); p += rr.nameLen;
+    *p++ = '\t';
+    if (rc) { *p++ = '1'; *p++ = '6'; } else *p++ = '0';
+    *p++ = '\t';
+    memcpy(p, rname, rl); p += rl;
+    *p++ = '\t';
+    p = put_int(p, (long)pos);
+    *p++ = '\t';
+    p = put_int(p, mapq);
+    *p++ = '\t';
+    // recoverCIGAR3from4 src/mapper.cpp:54-77: '=' and 'X' runs merge into M
+    long run = 0;
+    for (int k = 0; k < nops; ++k) {
+        const char c = (char)ops[k].code;
+        if (c == '=' || c == 'X') { run += ops[k].len; continue; }
+        if (run > 0) { p = put_int(p, run); *p++ = 'M'; run = 0; }
+        p = put_int(p, ops[k].len); *p++ = c;
+    }
+    if (run > 0) { p = put_int(p, run); *p++ = 'M'; }
+    static const char mid[] = "\t*\t0\t0\t";
+    memcpy(p, mid, sizeof(mid) - 1); p += sizeof(mid) - 1;
+    memcpy(p, strand(i, rc), (size_t)len); p += len;
+    *p++ = '\t';
+    if (rc) { for (int k = 0; k < len; ++k) p[k] = rr.qual[len - 1 - k]; }
+    else memcpy(p, rr.qual, (size_t)len);
+    p += len;
+    static const char t1[] = "\tAS:i:", t2[] = "\tNM:i:", t3[] = "\tX0:Z:";
+    memcpy(p, t1, 6); p += 6; p = put_int(p, a.score);
+    memcpy(p, t2, 6); p += 6; p = put_int(p, a.edit_dist);
+    memcpy(p, t3, 6); p += 6;
+    for (int k = 0; k < nops; ++k) { p = put_int(p, ops[k].len); *p++ = (char)ops[k].code; }
+    *p++ = '\n';
+    out.resize((size_t)(p - out.data()));
+    mappedPrinted[0]++; mappedPrinted[1]++;
 }
 
 void Mapper::map_unpaired_rest(Read& read, bool done) {

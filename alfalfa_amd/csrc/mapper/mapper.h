@@ -101,6 +101,24 @@ struct Read {                     // read_t src/mapper.h:126-219
     std::string printPaired(int i, bool firstMate);
 };
 
+// one input record as the reader split it: pointers into the input's memory, nothing copied yet (name = up to the first white
+// space, '/1' '/2' stripped; seq and qual are `len` bytes each)
+struct RawRead { const char* name; int nameLen; const char* seq; const char* qual; int len; };
+
+// the results of one whole-read device call (alfa_map_reads_batch), in the call's own dense form; freed with the object
+struct MapCallResult {
+    std::vector<int32_t> st;
+    std::vector<int64_t> aoff, soff, ooff;
+    alfa_map_alignment* al = nullptr;
+    alfa_match* sd = nullptr;
+    alfa_map_cigar_op* op = nullptr;
+    void (*free_fn)(void*) = nullptr;
+    MapCallResult() = default;
+    MapCallResult(const MapCallResult&) = delete;
+    MapCallResult& operator=(const MapCallResult&) = delete;
+    ~MapCallResult() { if (free_fn) { free_fn(al); free_fn(sd); free_fn(op); } }
+};
+
 struct RefIndex {                 // the parts of `sparseSA` the mapper itself touches
     const alfa_host_index* h = nullptr;
     const alfa_index_view* v = nullptr;
@@ -124,6 +142,16 @@ class Mapper {
     // have left them), 0 when it still has to be mapped here
     bool device_map_usable() const;
     void map_batch(Read* const* reads, int n, std::vector<uint8_t>& done);
+    // ---- the same for records the reader only split: map_raw() lower-cases every read and its reverse complement into one
+    // buffer (strand(i, rc)) and makes the call; a read the device finished with at most one alignment, CIGAR included, -- nearly
+    // all short reads -- then goes from the call's results straight to its SAM line (render_direct: read_t::postprocess
+    // src/mapper.cpp:322-358 and printUnpairedAlignment src/mapper.h:181-193 for that case, no read_t / alignment_t objects in
+    // between); every other read is materialised and takes the general path (adopt() gives it the call's alignments)
+    void map_raw(const RawRead* raw, int n, MapCallResult& R);
+    const char* strand(int i, bool rc) const { return strands_.data() + strandOff_[(size_t)i] + (rc ? rawLen_[(size_t)i] : 0); }
+    bool direct_ok(const MapCallResult& R, int i) const;
+    void render_direct(const RawRead& rr, int i, const MapCallResult& R, std::string& out, long* mappedPrinted);
+    void adopt(Read& r, const MapCallResult& R, int i);
     void map_unpaired_rest(Read& read, bool done);      // what is left of map_unpaired after map_batch: (unpaired_match,) postprocess
     bool finish_unpaired_direct(Read& read);            // ... for a read whose CIGARs came with its alignments: no fiber needed; false = needs one
     void map_mate_rest(Read& read, bool done);          // ... of map_mate
@@ -177,10 +205,17 @@ class Mapper {
                             std::vector<PairInfo>& windowAlns, int alignmentIndex);
     void set_paired(Read& m1, Read& m2, int i, int j, bool concordant);
     bool is_concordant(const Alignment& a, const Alignment& b) const;
+    void map_options(alfa_map_options& mo) const;
+    void describe(const char* P, const char* Prc, int Plength, alfa_map_read& x) const;
+    void map_call(const alfa_map_options& mo, int n, MapCallResult& R);      // rd_[0..n) described
     const RefIndex& idx_;
     const AlignOpt& opt_;
     const PairedOpt& popt_;
     HotSched& hot_;
+    std::vector<alfa_map_read> rd_;       // reused from call to call
+    std::vector<char> strands_;
+    std::vector<size_t> strandOff_;
+    std::vector<int> rawLen_;
 };
 
 std::string sam_header(const RefIndex& idx, int argc, char** argv);
@@ -189,7 +224,7 @@ std::string sam_header(const RefIndex& idx, int argc, char** argv);
 // is done here, on the host)
 mapcore::Options core_options(const AlignOpt& o);
 mapcore::ReadParams core_read_params(const AlignOpt& o, int Plength);
-extern std::atomic<long> g_map_us[4];
+extern std::atomic<long> g_map_us[5];
 extern std::atomic<long> g_core_done, g_core_fallback;     // --core-trials / device mapping: reads done there, reads handed back
 
 }  // namespace alfa

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <deque>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <algorithm>
@@ -39,8 +40,10 @@ struct Options {
     int fibers = 2048, gpus = 1, device = 0;     // 2048 fibers per worker: measured best on C3 (4096: 500 k, 2048: 667 k, 1024: 650 k, 512: 589 k reads/s)
     bool stats = false;
     bool gpuIndex = false;      // --gpu-index: build the index arrays on the GPU (index_build.hip)
-    int mapBatch = 4096;        // --map-batch: reads per worker and device call when whole reads are mapped on the device (a call of 4096
-                                // reads costs 0.19 us per read against 0.15 for 16384, and the reads of a batch stay cache- and heap-warm)
+    int mapBatch = 16384;       // --map-batch: reads per worker and device call when whole reads are mapped on the device.  With reads
+                                // rendered straight from the call's results nothing per read stays behind on the host, and a call's fixed
+                                // part (a dozen launches, three host waits) is what counts: 2 000 000 short reads, map phase with 8 / 16
+                                // workers: 4096: - / 0.28 s, 8192: 0.29 / 0.27, 16384: 0.30 / 0.27, 32768: 0.31 / 0.32, 65536: 0.35 / 0.38
 };
 
 int seed_type(const std::string& t) {       // parseSeedType src/options.cpp:155-172 (CLI names are shifted)
@@ -304,6 +307,16 @@ void materialize(const RawRec& x, Read& r) {
     if (r.qname.length() > 2 && r.qname[r.qname.length() - 2] == '/') r.qname.erase(r.qname.length() - 2);
 }
 
+// the same record as pointers (nothing copied): the name as materialize() would store it
+RawRead raw_read(const RawRec& x) {
+    const char* h = x.p + 1;
+    const size_t hl = x.l1 - 1;
+    size_t k = 0;
+    while (k < hl && !isspace((unsigned char)h[k])) k++;
+    if (k > 2 && h[k - 2] == '/') k -= 2;
+    return RawRead{h, (int)k, x.p + x.o2, x.p + x.o4, (int)x.l2};
+}
+
 // persistent worker pool: every batch is split into contiguous slices, one per worker
 class Pool {
    public:
@@ -357,6 +370,13 @@ class Chan {
         cv_.wait(g, [&] { return q_.size() < cap_; });
         q_.push_back(std::move(v));
         cv_.notify_all();
+    }
+    bool try_push(T& v) {                   // false (v untouched) when the queue is full
+        std::lock_guard<std::mutex> g(mu_);
+        if (q_.size() >= cap_) return false;
+        q_.push_back(std::move(v));
+        cv_.notify_all();
+        return true;
     }
     bool try_pop(T& v) {
         std::lock_guard<std::mutex> g(mu_);
@@ -464,6 +484,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     const bool devmap = o.aln.deviceMap && ops[0].map_reads_batch && !o.aln.noFW && !o.aln.noRC && !o.aln.coreTrials && !o.aln.deviceRegions &&
                         (o.pair1.empty() || o.paired.mode == 1);
     const size_t readCap = (size_t)T * (size_t)std::max(256, devmap ? std::max(o.fibers, o.mapBatch) : o.fibers);
+    const bool direct_render = getenv("ALFA_NO_DIRECT_RENDER") == nullptr;       // (the general path for every read: A/B runs and tests)
 
     struct Batch {
         std::vector<Read> a, b;               // b stays empty for single-end input; objects beyond n are spares of earlier batches
@@ -472,6 +493,8 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         int n = 0;                            // reads (pairs) of this batch
         std::vector<std::string> text;        // rendered SAM, one chunk per worker slice, in input order
         std::vector<long> cnt;                // per slice: mapped1, printed1, mapped2, printed2
+        std::atomic<int> remaining{0};        // slices still being worked on
+        long seq = 0;                         // position in the input
     };
     typedef std::unique_ptr<Batch> BatchP;
     long total = 0, mapped1 = 0, mapped2 = 0, printed1 = 0, printed2 = 0;
@@ -479,10 +502,20 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     std::vector<double> w_build((size_t)T, 0.0), w_run((size_t)T, 0.0), w_render((size_t)T, 0.0), w_dev((size_t)T, 0.0);   // per worker, --stats
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
-    // fill(batch) -> false at end of input; work(batch, t, lo, hi) maps and renders reads [lo,hi) on worker t
-    auto stream = [&](const std::function<bool(Batch&)>& fill, const std::function<void(Batch&, int, int, int)>& work) {
-        // batches circulate reader -> mapping -> writer -> reader, so that the reads' strings are allocated once
-        Chan<BatchP> parsed(2), mapped(2), spare(8);
+    // fill(batch) -> false at end of input; work(batch, t, k, lo, hi) maps and renders reads [lo,hi) = slice k of the batch on worker t
+    auto stream = [&](const std::function<bool(Batch&)>& fill, const std::function<void(Batch&, int, int, int, int)>& work) {
+        // batches circulate reader -> dispatcher -> workers -> writer -> reader, so that the reads' strings are allocated once.
+        // A batch is cut into T slices that the workers take from one queue, with no barrier between batches: the workers drift
+        // apart, so that while some wait for the GPU (one device call per slice) the others build reads or render SAM, instead
+        // of all T calls arriving at the GPU at once and all T renderings leaving it idle.  The writer takes finished batches
+        // in input order.
+        struct Slice { Batch* B; int k, lo, hi; };
+        Chan<BatchP> parsed(2), spare(8);
+        Chan<Slice> slices((size_t)2 * (size_t)T);
+        std::mutex dm;
+        std::condition_variable dcv;
+        std::map<long, Batch*> finished;
+        long n_dispatched = -1;                       // known once the input has ended
         std::thread reader([&] {
             for (;;) {
                 double t0 = now();
@@ -497,33 +530,61 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
             }
             parsed.close();
         });
-        std::thread writer([&] {
+        std::thread dispatcher([&] {
+            long seq = 0;
             BatchP bp;
-            while (mapped.pop(bp)) {
+            while (parsed.pop(bp)) {
+                Batch* B = bp.release();
+                const int n = B->n;
+                B->seq = seq++;
+                B->text.assign((size_t)T, std::string());
+                B->cnt.assign((size_t)T * 4, 0);
+                B->remaining.store(T);
+                for (int k = 0; k < T; ++k) slices.push(Slice{B, k, (int)((int64_t)n * k / T), (int)((int64_t)n * (k + 1) / T)});
+            }
+            { std::lock_guard<std::mutex> g(dm); n_dispatched = seq; }
+            dcv.notify_all();
+            slices.close();
+        });
+        std::thread writer([&] {
+            for (long next = 0;; ++next) {
+                Batch* B = nullptr;
+                {
+                    std::unique_lock<std::mutex> g(dm);
+                    dcv.wait(g, [&] { return finished.count(next) || next == n_dispatched; });
+                    auto it = finished.find(next);
+                    if (it == finished.end()) break;
+                    B = it->second;
+                    finished.erase(it);
+                }
                 double t0 = now();
-                for (const std::string& s : bp->text)
+                total += B->n;
+                for (int t = 0; t < T; ++t) {
+                    mapped1 += B->cnt[t * 4]; printed1 += B->cnt[t * 4 + 1]; mapped2 += B->cnt[t * 4 + 2]; printed2 += B->cnt[t * 4 + 3];
+                }
+                for (const std::string& s : B->text)
                     if (fwrite(s.data(), 1, s.size(), out) != s.size()) write_failed = true;
-                spare.push(std::move(bp));
+                // back to the reader; never wait here: once the input has ended nobody takes spares any more (a batch that does
+                // not fit is left to the operating system like the others, see below)
+                BatchP back(B);
+                if (!spare.try_push(back)) (void)back.release();
                 t_print += now() - t0;
             }
         });
-        BatchP bp;
-        while (parsed.pop(bp)) {
-            double t0 = now();
-            Batch& B = *bp;
-            const int n = B.n;
-            total += n;
-            B.text.assign((size_t)T, std::string());
-            B.cnt.assign((size_t)T * 4, 0);
-            pool.run([&](int t) { work(B, t, (int)((int64_t)n * t / T), (int)((int64_t)n * (t + 1) / T)); });
-            for (int t = 0; t < T; ++t) {
-                mapped1 += B.cnt[t * 4]; printed1 += B.cnt[t * 4 + 1]; mapped2 += B.cnt[t * 4 + 2]; printed2 += B.cnt[t * 4 + 3];
+        const double tm0 = now();
+        pool.run([&](int t) {
+            Slice sl;
+            while (slices.pop(sl)) {
+                work(*sl.B, t, sl.k, sl.lo, sl.hi);
+                if (sl.B->remaining.fetch_sub(1) == 1) {
+                    { std::lock_guard<std::mutex> g(dm); finished[sl.B->seq] = sl.B; }
+                    dcv.notify_all();
+                }
             }
-            t_map += now() - t0;
-            mapped.push(std::move(bp));
-        }
-        mapped.close();
+        });
+        t_map += now() - tm0;
         reader.join();
+        dispatcher.join();
         writer.join();
         // the batches left in circulation hold hundreds of thousands of reads: tearing them down string by string costs more than
         // anything else at the end of a run (0.3-0.6 s per 10^6 reads in flight) and the process is about to end -- they are left
@@ -549,11 +610,64 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 }
                 return B.n > 0;
             },
-            [&](Batch& B, int t, int lo, int hi) {
+            [&](Batch& B, int t, int k, int lo, int hi) {
                 Mapper& mp = *mappers[t];
-                std::string& txt = B.text[t];
-                long* c = &B.cnt[(size_t)t * 4];
+                std::string& txt = B.text[(size_t)k];
+                long* c = &B.cnt[(size_t)k * 4];
                 const double tb0 = now();
+                bool raw_ok = direct_render && mp.device_map_usable();
+                for (int i = lo; i < hi && raw_ok; i++) raw_ok = B.ra[i].p != nullptr;
+                if (raw_ok) {
+                    // records the reader only split go to the device as they are; a read that comes back finished, with at most
+                    // one alignment and its CIGAR, is rendered straight from the call's results -- no Read, no Alignment objects
+                    const int n = hi - lo;
+                    static thread_local std::vector<RawRead> raw;
+                    raw.resize((size_t)n);
+                    for (int i = 0; i < n; i++) raw[(size_t)i] = raw_read(B.ra[lo + i]);
+                    MapCallResult R;
+                    const double td0 = now();
+                    mp.map_raw(raw.data(), n, R);
+                    const double td1 = now();
+                    w_dev[t] += td1 - td0;
+                    std::vector<uint8_t> direct((size_t)n);
+                    std::vector<int> rest;
+                    for (int i = 0; i < n; i++) {
+                        if ((direct[(size_t)i] = mp.direct_ok(R, i))) continue;
+                        Read& r = B.a[lo + i];
+                        materialize(B.ra[lo + i], r);
+                        r.init();
+                        const bool done = R.st[(size_t)i] == 0;
+                        if (done) mp.adopt(r, R, i);
+                        if (!(done && mp.finish_unpaired_direct(r))) rest.push_back(i);
+                    }
+                    scheds[t]->run((int)rest.size(), o.fibers, [&](int k) { mp.map_unpaired_rest(B.a[lo + rest[(size_t)k]], R.st[(size_t)rest[(size_t)k]] == 0); });
+                    const double tb2 = now();
+                    w_build[t] += td0 - tb0; w_run[t] += tb2 - td0;
+                    size_t bytes = 0;
+                    for (int i = 0; i < n; i++) bytes += 2 * (size_t)raw[(size_t)i].len + (size_t)raw[(size_t)i].nameLen + 160;
+                    txt.reserve(txt.size() + bytes);
+                    long with_cigar = 0;
+                    for (int i = 0; i < n; i++) {
+                        if (direct[(size_t)i]) {
+                            const long before = c[0];
+                            mp.render_direct(raw[(size_t)i], i, R, txt, c);
+                            with_cigar += c[0] - before;
+                            continue;
+                        }
+                        Read& r = B.a[lo + i];
+                        if (r.alignments.empty()) txt += r.emptyAlignment(false, false, true);
+                        else {
+                            c[0]++;
+                            int k = std::min((int)r.alignments.size(), o.aln.alignmentCount);
+                            c[1] += k;
+                            for (int j = 0; j < k; j++) txt += r.printUnpaired(j);
+                        }
+                        r.release();
+                    }
+                    g_map_us[3] += with_cigar;
+                    w_render[t] += now() - tb2;
+                    return;
+                }
                 for (int i = lo; i < hi; i++) materialize(B.ra[i], B.a[i]);
                 const double tb1 = now();
                 if (mp.device_map_usable()) {
@@ -563,7 +677,6 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                     for (int i = lo; i < hi; i++) { B.a[i].init(); ptr[(size_t)(i - lo)] = &B.a[i]; }
                     std::vector<uint8_t> done;
                     const double td0 = now();
-                    w_build[t] += td0 - tb1;
                     mp.map_batch(ptr.data(), hi - lo, done);
                     w_dev[t] += now() - td0;
                     // a read whose CIGARs came with its alignments is finished right here (sort, strings, MAPQ); only the others
@@ -618,10 +731,10 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 }
                 return B.n > 0;
             },
-            [&](Batch& B, int t, int lo, int hi) {
+            [&](Batch& B, int t, int k, int lo, int hi) {
                 Mapper& mp = *mappers[t];
-                std::string& txt = B.text[t];
-                long* c = &B.cnt[(size_t)t * 4];
+                std::string& txt = B.text[(size_t)k];
+                long* c = &B.cnt[(size_t)k * 4];
                 for (int i = lo; i < hi; i++) { materialize(B.ra[i], B.a[i]); materialize(B.rb[i], B.b[i]); }
                 if (mp.splittable() && mp.device_map_usable()) {
                     // paired mode 1 = unpairedMatch on each mate, then pairing: both mates of every pair go to the device as reads
@@ -680,8 +793,8 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
             s.glob_tasks += x.glob_tasks; s.align_calls += x.align_calls; s.align_tasks += x.align_tasks; s.hot_seconds += x.hot_seconds;
         }
         fprintf(stderr, "#PHASES parse %.3f map %.3f print %.3f\n", t_parse, t_map, t_print);
-        fprintf(stderr, "#CORE reads_done %ld handed_back %ld cigars_with_alignments %ld device_call_thread_seconds: describe %.3f call %.3f adopt %.3f\n",
-                g_core_done.load(), g_core_fallback.load(), g_map_us[3].load(), g_map_us[0].load() * 1e-6, g_map_us[1].load() * 1e-6, g_map_us[2].load() * 1e-6);
+        fprintf(stderr, "#CORE reads_done %ld handed_back %ld cigars_with_alignments %ld device_call_thread_seconds: describe %.3f call %.3f adopt %.3f lane_wait %.3f\n",
+                g_core_done.load(), g_core_fallback.load(), g_map_us[3].load(), g_map_us[0].load() * 1e-6, g_map_us[1].load() * 1e-6, g_map_us[2].load() * 1e-6, g_map_us[4].load() * 1e-6);
         fprintf(stderr, "#QUEUES GPU_MAX_HW_QUEUES %s\n", getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "unset");
         fprintf(stderr, "#STARTUP index_loaded %.3f device_ready %.3f workers_ready %.3f done %.3f (seconds since start)\n", t_index_ready,
                 t_device_ready, t_pool_ready, since_start());
@@ -692,6 +805,13 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 (long)s.rounds, (long)s.seed_calls, (long)s.seed_queries, (long)s.ext_calls, (long)s.ext_tasks, (long)s.nw_calls,
                 (long)s.nw_tasks, (long)s.glob_calls, (long)s.glob_tasks, (long)s.align_calls, (long)s.align_tasks, s.hot_seconds);
     }
+    if (o.stats) {      // against the caller's clock: what loading the program cost before main, and what ending it costs after this line
+        const double epoch = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+        fprintf(stderr, "#CLOCK mapper_start %.3f last_line %.3f (seconds since the epoch)\n", epoch - since_start(), epoch);
+    }
+    // Orderly teardown on purpose.  Ending the process right here (_exit after flushing) was measured and is SLOWER: the kernel
+    // driver takes 0.24-0.37 s to reap a process that still holds a live GPU context, against 0.04 s (1 worker) to 0.2 s (16
+    // workers) when HIP has shut down first (tools/exit_cost.sh, tools/probes/exit_probe.hip).
     for (int g = 0; g < G; ++g) bind.release_ops(&ops[g]);
     alfa_host_index_free(hidx);
     return 0;

@@ -7,6 +7,7 @@ no Python or CPU fallback.
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -629,6 +630,9 @@ def make_map_reads(fw, rc, K, opt, min_mem=40, min_coverage=0.25):
     return arr
 
 
+last_map_call_seconds = None
+
+
 def map_reads_batch(dev_index, opt, params, reads):
     """-> (status[n], aln_off[n+1], alignments, seed_off[n+1], chain seeds, op_off[n+1], CIGAR operations)"""
     n = len(reads)
@@ -637,14 +641,23 @@ def map_reads_batch(dev_index, opt, params, reads):
     soff = np.zeros(n + 1, np.int64)
     ooff = np.zeros(n + 1, np.int64)
     ap, sp, op = C.c_void_p(), C.c_void_p(), C.c_void_p()
-    check(lib().alfa_map_reads_batch(dev_index._h, C.byref(opt), C.byref(params), reads, n, st.ctypes.data_as(C.c_void_p),
-                                     aoff.ctypes.data_as(C.c_void_p), C.byref(ap), soff.ctypes.data_as(C.c_void_p), C.byref(sp),
-                                     ooff.ctypes.data_as(C.c_void_p), C.byref(op)))
-    na, ns, no = int(aoff[-1]), int(soff[-1]), int(ooff[-1])
-    ops = np.frombuffer(C.string_at(op.value, no * MAP_OP_DTYPE.itemsize), dtype=MAP_OP_DTYPE).copy() if no else np.zeros(0, MAP_OP_DTYPE)
+    global last_map_call_seconds
+    t0 = time.perf_counter()
+    rc = lib().alfa_map_reads_batch(dev_index._h, C.byref(opt), C.byref(params), reads, n, st.ctypes.data_as(C.c_void_p),
+                                    aoff.ctypes.data_as(C.c_void_p), C.byref(ap), soff.ctypes.data_as(C.c_void_p), C.byref(sp),
+                                    ooff.ctypes.data_as(C.c_void_p), C.byref(op))
+    last_map_call_seconds = time.perf_counter() - t0        # the library call alone (numpy copies of its results come after)
+    check(rc)
+
+    def take(ptr, count, dtype):
+        if not count:
+            return np.zeros(0, dtype)
+        buf = (C.c_char * (count * dtype.itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dtype).copy()
+    al = take(ap, int(aoff[-1]), MAP_ALN_DTYPE)
+    sd = take(sp, int(soff[-1]), MATCH_DTYPE)
+    ops = take(op, int(ooff[-1]), MAP_OP_DTYPE)
     lib().alfa_free(op)
-    al = np.frombuffer(C.string_at(ap.value, na * MAP_ALN_DTYPE.itemsize), dtype=MAP_ALN_DTYPE).copy() if na else np.zeros(0, MAP_ALN_DTYPE)
-    sd = np.frombuffer(C.string_at(sp.value, ns * MATCH_DTYPE.itemsize), dtype=MATCH_DTYPE).copy() if ns else np.zeros(0, MATCH_DTYPE)
     lib().alfa_free(ap)
     lib().alfa_free(sp)
     return st, aoff, al, soff, sd, ooff, ops

@@ -69,12 +69,13 @@ def main():
     ap.add_argument("--exe", default="gpu,cpu")
     ap.add_argument("--extra", default="")
     ap.add_argument("--dir", default="/tmp/alfa_e2e")
+    ap.add_argument("--index-with", default="cpu", choices=["cpu", "gpu"], help="which tool builds the index (gpu: suffix array built on the device)")
     args = ap.parse_args()
     os.makedirs(args.dir, exist_ok=True)
     fa, fq = write_workload(args.dir, args.ref_len, args.reads, args.read_len, args.err, args.long)
     mates = write_pairs(args.dir, args.ref_len, args.reads) if args.paired else None
     idx = os.path.join(args.dir, "idx12")
-    subprocess.run([EXES["cpu"] if os.path.exists(EXES["cpu"]) else EXES["gpu"], "index", "-r", fa, "-p", idx, "-s", "12"], check=True,
+    subprocess.run([EXES["cpu"] if os.path.exists(EXES["cpu"]) and args.index_with == "cpu" else EXES["gpu"], "index", "-r", fa, "-p", idx, "-s", "12"], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     md5s = {}
     for name in args.exe.split(","):

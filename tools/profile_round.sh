@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 6 --warmup 2 --e2e-reads 0 --no-cpu-baseline --align-tasks 20000"
+ARGS="--steps 6 --warmup 2 --e2e-reads 0 --no-cpu-baseline --no-c4 --align-tasks 20000"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -- python3 "$R/bench.py" $ARGS > "$OUT/kt.log" 2>&1
 echo "kernel trace done"
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -- python3 "$R/bench.py" $ARGS > "$OUT/fetch.log" 2>&1
