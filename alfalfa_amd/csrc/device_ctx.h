@@ -49,7 +49,8 @@ struct Ctx {
     // side streams: independent kernel chains of one batch (one per kernel bin) fork from `stream` and join it again,
     // so that a bin holding a handful of long tasks does not serialise behind (or in front of) the others
     static constexpr int NSIDE = 14;
-    hipStream_t side[NSIDE] = {};
+    hipStream_t side[NSIDE] = {};    // created at first use: side_stream(k)
+    hipStream_t side_stream(int k);
     hipEvent_t side_ev[NSIDE] = {};
     hipEvent_t l2_ev[6] = {};        // spare
     hipEvent_t fill_ev[3] = {};      // a group bin's fill kernel is done: its two backtrack classes may run side by side

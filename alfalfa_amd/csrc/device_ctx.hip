@@ -144,7 +144,6 @@ int Ctx::ensure(int dev) {
         auto ok = [&](hipError_t e) { if (err == hipSuccess) err = e; return err == hipSuccess; };
         (void)ok(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
         for (auto& e : ev) if (!ok(hipEventCreate(&e))) break;
-        for (auto& st : side) if (!ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking))) break;
         for (auto& e : side_ev) if (!ok(hipEventCreateWithFlags(&e, hipEventDisableTiming))) break;
         for (auto& e : fill_ev) if (!ok(hipEventCreateWithFlags(&e, hipEventDisableTiming))) break;
         for (auto& e : l2_ev) if (!ok(hipEventCreateWithFlags(&e, hipEventDisableTiming))) break;
@@ -163,6 +162,17 @@ int Ctx::ensure(int dev) {
         stream = main_stream;          // set last: a context with a stream is complete
     }
     return ALFA_OK;
+}
+
+// Side streams are made at their first use: a thread that only maps whole reads (alfa_map_reads_batch: one stream) never
+// needs them, and 16 such threads would otherwise hold 224 idle streams -- which HIP's shutdown then takes 0.1 s to destroy.
+hipStream_t Ctx::side_stream(int k) {
+    if (!side[k] && hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        side[k] = nullptr;
+        return stream;               // (out of streams: the chain runs on the main stream, in order -- slower, never wrong)
+    }
+    return side[k];
 }
 
 int Ctx::join_sides() {
@@ -222,7 +232,7 @@ extern "C" int alfa_stream_priority_span(int device, int* lo, int* hi) {
     };
     ALFA_HIP(see(cx->stream));
     ALFA_HIP(see(cx->up));
-    for (auto st : cx->side) ALFA_HIP(see(st));
+    for (int k = 0; k < alfa::Ctx::NSIDE; ++k) ALFA_HIP(see(cx->side_stream(k)));      // (makes the ones not used yet: the rule covers them all)
     *lo = mn; *hi = mx;
     return ALFA_OK;
 }

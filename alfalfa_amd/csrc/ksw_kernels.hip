@@ -1271,12 +1271,14 @@ void launch_all(alfa_dp_batch* b, alfa::Ctx* cx) {
         // a synchronous call orders its side chains behind the caller's stream; with lazy joins the chains are only ordered
         // among themselves (each side stream is in order) and joined at the next fetch / sync: a batch's inputs were uploaded
         // and waited for when it was created, so nothing on `st` -- e.g. the seed kernels of other reads -- has to finish first
+        hipStream_t sk = cx->side_stream(k);
+        if (sk == st) return st;            // no stream could be made: the main stream itself, nothing to fork or join
         if (!cx->lazy_join) {
             if (!forked) { (void)hipEventRecord(cx->fork_ev, st); forked = true; }
-            if (!used[k]) (void)hipStreamWaitEvent(cx->side[k], cx->fork_ev, 0);
+            if (!used[k]) (void)hipStreamWaitEvent(sk, cx->fork_ev, 0);
         }
         used[k] = true;
-        return cx->side[k];
+        return sk;
     };
     for (int g = 0; g < 3; ++g) {
         const int n = bc[3 + g], nbig = b->nbig[g], rowb = GL16 << g;

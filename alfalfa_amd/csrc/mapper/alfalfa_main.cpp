@@ -1,7 +1,9 @@
 // alfalfa_main.cpp -- `alfalfa_amd`: the reference's `alfalfa index|align` commands on top of libalfa_hot (HIP only).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <malloc.h>
 
 #include "mapper_cli.h"
@@ -58,5 +60,11 @@ int main(int argc, char** argv) {
     b.bind_thread = [](int device) { (void)hipSetDevice(physical(device)); };
     b.last_error = alfa_last_error;
     b.index_build_on_device = [](int device) { return alfa_index_build_on_device(physical(device)); };
-    return alfa::mapper_main(argc, argv, b);
+    const int rc = alfa::mapper_main(argc, argv, b);
+    if (getenv("ALFA_TEARDOWN_CLOCK")) {      // (with --stats' #CLOCK line: how long the mapper's own teardown took, and what is left for HIP's)
+        timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        fprintf(stderr, "#CLOCK main_returns %.3f\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec);
+    }
+    return rc;
 }

@@ -17,16 +17,16 @@ s, e = float(sys.argv[1]), float(sys.argv[2])
 txt = open("/tmp/e2e_c3/err.txt").read()
 m = re.search(r"#CLOCK mapper_start ([0-9.]+) last_line ([0-9.]+)", txt)
 a, b = float(m.group(1)), float(m.group(2))
+m2 = re.search(r"#CLOCK main_returns ([0-9.]+)", txt)
+if m2:
+    print("   after_last_line = mapper teardown %.3f + after main() %.3f" % (float(m2.group(1)) - b, e - float(m2.group(1))))
 st = re.search(r"#STARTUP.*", txt).group(0)
 ph = re.search(r"#PHASES.*", txt).group(0)
 print("%s t=%s %s: wall %.3f = before_main %.3f + run %.3f + after_last_line %.3f | %s | %s" % (sys.argv[3].split("/")[-1], sys.argv[4], sys.argv[5], e - s, a - s, b - a, e - b, st[:110], ph))
 PY
 }
+export ALFA_TEARDOWN_CLOCK=1
 run /tmp/e2e_c3/tiny.fq 16
 run /tmp/e2e_c3/tiny.fq 1
 run /tmp/e2e_c3/reads.fq 16
 run /tmp/e2e_c3/reads.fq 8
-run /tmp/e2e_c3/reads.fq 12
-GPU_MAX_HW_QUEUES=8 run /tmp/e2e_c3/reads.fq 16
-GPU_MAX_HW_QUEUES=8 run /tmp/e2e_c3/reads.fq 8
-GPU_MAX_HW_QUEUES=2 run /tmp/e2e_c3/reads.fq 16
