@@ -79,6 +79,7 @@ struct Work {                       // one read's state (LDS on the device)
     CigOp* ops;                                     // the read's extended CIGAR operations (caller's memory: written, never read back)
     int32_t opsCap;
     uint32_t bam[BAM_CAP];
+    const uint32_t* bamp;      // the BAM operations of the last global_cigar call: `bam`, or memory of the environment's (long pieces)
     uint16_t aorder[ALN_CAP];
     int32_t nAln, nChainOut, nOps, fail;
 };
@@ -406,7 +407,7 @@ MC_FN bool dp_piece(Env& env, Work& W, bool fw, int qFrom, int qLen, int64_t tFr
     if (n < 0) return false;
     int x = 0, y = 0;
     for (int k = 0; k < n; ++k) {
-        const uint32_t c = W.bam[first + k];
+        const uint32_t c = W.bamp[first + k];
         const int op = (int)(c & 0xf), len = (int)(c >> 4);
         if (op == 0) {
             // maximal runs of equal / unequal residues, in order (nt4 codes are compared: n equals n)

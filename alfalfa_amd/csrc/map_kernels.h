@@ -30,10 +30,15 @@ struct MapKernelArgs {
     const int32_t* rstatus;         // [2n] regions_kernel's status
     // DP
     const void* dp_params;          // DevParams (ksw_wave.h)
-    uint8_t* scratch;               // n slots of scratch_stride bytes: nt4 query and target of the task in flight
+    // scratch of the read in flight, one slot per WORKGROUP of the launch (`slots` of them; a workgroup takes reads from
+    // *next until none is left, so the scratch is sized by what the GPU holds at a time, not by the batch)
+    int32_t slots;
+    int32_t* next;                  // the next read to take; 0 at launch
+    uint8_t* scratch;               // slots of scratch_stride bytes: nt4 query and target of the task in flight
     int32_t scratch_stride, qcap;   // a slot holds a query of up to qcap bytes at 16 and a target behind it
-    uint8_t* zscratch;              // n slots of zstride bytes: direction bytes of the ksw_global call in flight
-    int64_t zstride;
+    uint8_t* zscratch;              // slots of zslot bytes: zstride direction bytes of the ksw_global call in flight (pieces beyond the
+    int64_t zstride, zslot;         // kernel's LDS tile), then room for bam_cap BAM operations of its walk
+    int32_t bam_cap;
     mapcore::Options opt;
     // results, slotted per read
     int32_t* status;                // [n] mapcore::Status
@@ -46,6 +51,8 @@ struct MapKernelArgs {
     int32_t ops_cap;                // room for a read's CIGAR operations (>= mapcore::OPS_CAP)
 };
 
+// workgroups one launch can keep resident (what `slots` is worth at most)
+int map_resident_workgroups();
 void launch_map(hipStream_t st, const MapKernelArgs& a);
 // dense copies of the slotted results: read r's alignments to out_alns[aln_off[r] ..], its chain seeds to out_seeds[seed_off[r] ..],
 // its CIGAR operations to out_ops[op_off[r] ..]

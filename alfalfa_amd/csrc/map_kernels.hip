@@ -39,7 +39,7 @@ constexpr int ZTILE = 4096;        // direction bytes of a ksw_global call that 
 
 struct DevEnv {
     const MapKernelArgs& A;
-    int ln, r;
+    int ln, r, slot;
     const uint8_t* Pf;
     const uint8_t* Pr;
     uint8_t* scr;
@@ -146,13 +146,16 @@ struct DevEnv {
         const int C4 = 2 * w + 1 > 128;
         // short pieces (the common case on short reads: a gap or an overhang of a few dozen residues) keep their direction
         // bytes in LDS, rows packed to the band's width -- the walk is a chain of dependent reads, 60 of them through HBM were
-        // half of the kernel's time; longer ones go to the read's slot of A.zscratch at the batch kernels' row stride
+        // half of the kernel's time.  Longer ones (long reads: pieces of hundreds to thousands of rows) go to the workgroup's
+        // slot of A.zscratch at the batch kernels' row stride and are walked through LDS a tile of rows at a time; their BAM
+        // operations go to the slot as well.
         const int wpad = (2 * w + 1 + 4) & ~3;               // > 2w + 1, a multiple of 4
         const bool in_lds = !C4 && tLen * wpad <= ZTILE;
         const int rowb = in_lds ? wpad : (C4 ? 256 : 128);
         if (!in_lds && (int64_t)tLen * rowb > A.zstride) return -1;
         if (!stage(fw, false, qFrom, qLen, tFrom, tLen)) return -1;
-        uint8_t* z = in_lds ? ztile : A.zscratch + (int64_t)r * A.zstride;
+        uint8_t* zg = A.zscratch + (int64_t)slot * A.zslot;
+        uint8_t* z = in_lds ? ztile : zg;
         const DevTask T = task(qLen, tLen, w, 0);
         ExtOut eo;
         int s = 0;
@@ -161,28 +164,50 @@ struct DevEnv {
         else wave_task_run<MODE_GLOBAL, 4>(T, scr, prm, z, eo, s);
         __threadfence_block();
         __syncthreads();
-        int pos = mapcore::BAM_CAP, n = 0;
+        uint32_t* bam = in_lds ? W.bam : (uint32_t*)(zg + A.zstride);
+        const int cap = in_lds ? mapcore::BAM_CAP : A.bam_cap;
+        int pos = cap, n = 0;
         uint32_t cur_op = 0xffffffffu, cur_len = 0;
         bool over = false;
         auto push = [&](uint32_t op, uint32_t len) {
             if (op == cur_op) { cur_len += len; return; }
-            if (cur_op != 0xffffffffu) { if (pos > 0) W.bam[--pos] = cur_len << 4 | cur_op; else over = true; ++n; }
+            if (cur_op != 0xffffffffu) { if (pos > 0) bam[--pos] = cur_len << 4 | cur_op; else over = true; ++n; }
             cur_op = op; cur_len = len;
         };
         int i = tLen - 1, k = (i + w + 1 < qLen ? i + w + 1 : qLen) - 1;
         int which = 0;
-        while (i >= 0 && k >= 0) {
-            const uint32_t zv = z[(int64_t)i * rowb + (k - i + w)];
-            which = (zv >> (which << 1)) & 3;
-            if (which == 0) { push(0, 1); --i; --k; }
-            else if (which == 1) { push(2, 1); --i; }
-            else { push(1, 1); --k; }
+        if (in_lds) {
+            while (i >= 0 && k >= 0) {
+                const uint32_t zv = z[i * rowb + (k - i + w)];
+                which = (zv >> (which << 1)) & 3;
+                if (which == 0) { push(0, 1); --i; --k; }
+                else if (which == 1) { push(2, 1); --i; }
+                else { push(1, 1); --k; }
+            }
+        } else {
+            const int TR = ZTILE / rowb;                     // rows of a tile: 32 (band <= 128 diagonals) or 16
+            int lo = i + 1;                                  // first row of the tile in LDS (none yet)
+            while (i >= 0 && k >= 0) {
+                if (i < lo) {                                // every lane takes the same path: i and k are wave-uniform
+                    lo = i - TR + 1 > 0 ? i - TR + 1 : 0;
+                    const int bytes = (i - lo + 1) * rowb;
+                    __syncthreads();
+                    for (int o = ln * 16; o < bytes; o += 64 * 16) *(uint4*)(ztile + o) = *(const uint4*)(z + (int64_t)lo * rowb + o);
+                    __syncthreads();
+                }
+                const uint32_t zv = ztile[(i - lo) * rowb + (k - i + w)];
+                which = (zv >> (which << 1)) & 3;
+                if (which == 0) { push(0, 1); --i; --k; }
+                else if (which == 1) { push(2, 1); --i; }
+                else { push(1, 1); --k; }
+            }
         }
         if (i >= 0) push(2, (uint32_t)(i + 1));
         if (k >= 0) push(1, (uint32_t)(k + 1));
-        if (cur_op != 0xffffffffu) { if (pos > 0) W.bam[--pos] = cur_len << 4 | cur_op; else over = true; ++n; }
+        if (cur_op != 0xffffffffu) { if (pos > 0) bam[--pos] = cur_len << 4 | cur_op; else over = true; ++n; }
         if (over) return -1;
         first = pos;
+        W.bamp = bam;
         return n;
     }
     // bit i: nt4(P[qpos + i]) == nt4(S[tpos + i]), i < n <= 64
@@ -197,41 +222,50 @@ struct DevEnv {
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void map_kernel(const MapKernelArgs A) {
     __shared__ Work W;
     __shared__ __align__(16) uint8_t ztile[ZTILE];
-    const int r = blockIdx.x, ln = threadIdx.x;
-    if (r >= A.n) return;
-    const int sf = 2 * r, sr = 2 * r + 1;
-    const int64_t bf = A.base[sf], br = A.base[sr], be = A.base[sr + 1];
-    int status = mapcore::DONE, naln = 0, nseed = 0, nops = 0;
-    if (A.rstatus[sf] | A.rstatus[sr]) status = mapcore::NEED_CALLER;           // regions_kernel handed a strand back
-    else if (be == bf) status = A.opt.rescue ? mapcore::NEED_CALLER : mapcore::DONE;      // no seed on either strand: the seed rescue rounds (src/mapper.cpp:542-555) stay with the caller
-    else {
-        DevEnv env{A, ln, r, A.reads + A.read_off[sf], A.reads + A.read_off[sr], A.scratch + (int64_t)r * A.scratch_stride, ztile,
-                   (const DevParams*)A.dp_params, A.reg + bf, A.reg + br, A.members + 2 * bf + 8 * (int64_t)sf,
-                   A.members + 2 * br + 8 * (int64_t)sr, A.nreg[sf], A.nreg[sr]};
-        const int nreg = env.nF + env.nR;
-        if (nreg > mapcore::REGION_CAP2) status = mapcore::NEED_CALLER;
+    __shared__ int next_read;
+    const int ln = threadIdx.x, slot = blockIdx.x;
+    // every workgroup takes reads until none is left (the grid is what the GPU holds at a time: `slots` workgroups)
+    for (;;) {
+        __syncthreads();
+        if (ln == 0) next_read = atomicAdd(A.next, 1);
+        __syncthreads();
+        const int r = next_read;
+        if (r >= A.n) break;
+        const int sf = 2 * r, sr = 2 * r + 1;
+        const int64_t bf = A.base[sf], br = A.base[sr], be = A.base[sr + 1];
+        int status = mapcore::DONE, naln = 0, nseed = 0, nops = 0;
+        if (A.rstatus[sf] | A.rstatus[sr]) status = mapcore::NEED_CALLER;           // regions_kernel handed a strand back
+        else if (be == bf) status = A.opt.rescue ? mapcore::NEED_CALLER : mapcore::DONE;      // no seed on either strand: the seed rescue rounds (src/mapper.cpp:542-555) stay with the caller
         else {
-            for (int k = ln; k < nreg; k += 64) W.rscore[k] = k < env.nF ? env.regF[k].score : env.regR[k - env.nF].score;
-            W.ops = A.ops + (int64_t)r * A.ops_cap;          // (every lane stores the same two values)
-            W.opsCap = A.ops_cap;
-            __syncthreads();
-            status = mapcore::map_read(env, W, A.opt, A.rp[r], nreg);
-            if (status == mapcore::DONE) {
-                naln = W.nAln; nseed = W.nChainOut; nops = W.nOps;
+            DevEnv env{A, ln, r, slot, A.reads + A.read_off[sf], A.reads + A.read_off[sr], A.scratch + (int64_t)slot * A.scratch_stride, ztile,
+                       (const DevParams*)A.dp_params, A.reg + bf, A.reg + br, A.members + 2 * bf + 8 * (int64_t)sf,
+                       A.members + 2 * br + 8 * (int64_t)sr, A.nreg[sf], A.nreg[sr]};
+            const int nreg = env.nF + env.nR;
+            if (nreg > mapcore::REGION_CAP2) status = mapcore::NEED_CALLER;
+            else {
+                for (int k = ln; k < nreg; k += 64) W.rscore[k] = k < env.nF ? env.regF[k].score : env.regR[k - env.nF].score;
+                W.ops = A.ops + (int64_t)r * A.ops_cap;          // (every lane stores the same values)
+                W.opsCap = A.ops_cap;
+                W.bamp = W.bam;
                 __syncthreads();
-                for (int k = ln; k < naln; k += 64) A.alns[(int64_t)r * mapcore::ALN_CAP + k] = W.alns[k];
-                for (int k = ln; k < nseed; k += 64) {
-                    alfa_match m; m.ref = W.cref[k]; m.query = W.cq[k]; m.len = W.cl[k];
-                    A.seeds[(int64_t)r * mapcore::CHAINOUT_CAP + k] = m;
+                status = mapcore::map_read(env, W, A.opt, A.rp[r], nreg);
+                if (status == mapcore::DONE) {
+                    naln = W.nAln; nseed = W.nChainOut; nops = W.nOps;
+                    __syncthreads();
+                    for (int k = ln; k < naln; k += 64) A.alns[(int64_t)r * mapcore::ALN_CAP + k] = W.alns[k];
+                    for (int k = ln; k < nseed; k += 64) {
+                        alfa_match m; m.ref = W.cref[k]; m.query = W.cq[k]; m.len = W.cl[k];
+                        A.seeds[(int64_t)r * mapcore::CHAINOUT_CAP + k] = m;
+                    }
                 }
             }
         }
-    }
-    if (ln == 0) {
-        A.status[r] = status;
-        A.naln[r] = naln;
-        A.nseed[r] = nseed;
-        A.nops[r] = nops;
+        if (ln == 0) {
+            A.status[r] = status;
+            A.naln[r] = naln;
+            A.nseed[r] = nseed;
+            A.nops[r] = nops;
+        }
     }
 }
 
@@ -249,9 +283,22 @@ __global__ void map_compact_kernel(int n, const int32_t* __restrict__ naln, cons
 
 }  // namespace
 
+// 3 wavefronts per SIMD (the kernel's registers) and the LDS of a CU both allow 12 one-wave workgroups per CU
+int map_resident_workgroups() {
+    static const int v = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t p;
+            if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
+        }
+        return cus * 12;
+    }();
+    return v;
+}
+
 void launch_map(hipStream_t st, const MapKernelArgs& a) {
-    if (a.n <= 0) return;
-    hipLaunchKernelGGL(map_kernel, dim3(a.n), dim3(64), 0, st, a);
+    if (a.n <= 0 || a.slots <= 0) return;
+    hipLaunchKernelGGL(map_kernel, dim3(a.slots), dim3(64), 0, st, a);
 }
 
 void launch_map_compact(hipStream_t st, int n, const int32_t* naln, const int32_t* nseed, const int32_t* nops, const int32_t* aln_off,

@@ -735,19 +735,19 @@ struct CoreEnv {
         r.score = e.score; r.qle = e.qle; r.tle = e.tle; r.gtle = e.gtle; r.gscore = e.gscore; r.max_off = e.max_off;
         return true;
     }
-    // ksw_global through the scheduler; the BAM operations to W.bam[0 .. n)
+    // ksw_global through the scheduler; the BAM operations stay in this object, W.bamp points at them
+    std::vector<uint32_t> cg;
     int global_cigar(mapcore::Work& W, bool fw, int qFrom, int qLen, int64_t tFrom, int tLen, int band, int& first) {
         const uint8_t* rp = fw ? read.readP.data() : read.rcReadP.data();
         const char* S = idx.S();
         std::vector<uint8_t> t((size_t)std::max(tLen, 0));
         for (int k = 0; k < tLen; ++k) t[k] = nt4((unsigned char)S[tFrom + k]);
         int32_t score = 0;
-        std::vector<uint32_t> cg;
+        cg.clear();
         hot.submit_global(GlobalReq{alfa_dp_task{rp + qFrom, t.data(), qLen, tLen, band, 0}, &score, &cg});
         hot.wait();
         first = 0;
-        if (cg.size() > (size_t)mapcore::BAM_CAP) return -1;
-        for (size_t k = 0; k < cg.size(); ++k) W.bam[k] = cg[k];
+        W.bamp = cg.data();
         return (int)cg.size();
     }
     uint64_t equal_mask(bool fw, int qpos, int64_t tpos, int n) const {

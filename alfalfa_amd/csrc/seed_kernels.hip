@@ -2367,11 +2367,15 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     const int64_t stride64 = (16 + (int64_t)qcap + 16 + (int64_t)max_plen + max_edit + 64 + 255) & ~(int64_t)255;
     if (stride64 > (1 << 30)) return alfa::fail(ALFA_EINVAL, "read too long for the mapping kernel's scratch");
     const size_t nints = (size_t)n + 6 * ((size_t)n + 1);              // status[n] | naln | nseed | nops | aln_off | seed_off | op_off, n+1 each (int32)
-    // direction bytes of the ksw_global call in flight, per read: the whole read at 256 bytes per row when that is affordable,
-    // else what 256 MiB per call give (at least 16 KiB: 128 rows of a band of up to 128 diagonals); a longer piece's CIGAR
-    // is left to the caller (op_count = -1)
+    // scratch of a read in flight, per workgroup of the launch: its staged strings, the direction bytes of its ksw_global call
+    // (the whole read at 256 bytes per row: every piece fits) and the BAM operations of that call's walk.  The launch has as
+    // many workgroups as the GPU keeps resident -- fewer when the slots would exceed 4 GiB (reads beyond ~5 kbp)
     const int64_t zworst = 256 * ((int64_t)max_plen + max_edit + 8);
-    const int64_t zstride = o->cigar_alignments > 0 ? std::min(zworst, std::max<int64_t>(16 << 10, (((int64_t)64 << 20) / n) & ~(int64_t)255)) : 0;
+    const int bam_cap = max_plen + max_edit + 8;
+    const int64_t zstride = o->cigar_alignments > 0 ? zworst : 0;
+    const int64_t zslot = o->cigar_alignments > 0 ? ((zstride + 4 * (int64_t)bam_cap + 255) & ~(int64_t)255) : 0;
+    int slots = std::min(n, alfa::map_resident_workgroups());
+    if (zslot > 0) slots = (int)std::max<int64_t>(1, std::min<int64_t>(slots, std::max<int64_t>(256, ((int64_t)4 << 30) / zslot)));
     size_t tmp_bytes = 0;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int32_t*)nullptr, (int32_t*)nullptr, n + 1, st));
     // ONE device arena and ONE pinned arena per calling thread for everything below (each hipMalloc / hipHostMalloc is a trip
@@ -2388,7 +2392,7 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
                             ? (int)std::max<int64_t>(OPS_CAP, std::min<int64_t>((int64_t)max_plen / 2 + 64, ((int64_t)256 << 20) / (8 * (int64_t)n)))
                             : OPS_CAP;
     const size_t o_ops = carve(sizeof(alfa::mapcore::CigOp) * (size_t)n * (size_t)ops_cap), o_ops2 = carve(sizeof(alfa::mapcore::CigOp) * (size_t)n * (size_t)ops_cap);
-    const size_t o_scr = carve((size_t)stride64 * (size_t)n + 64), o_z = carve((size_t)zstride * (size_t)n + 64);
+    const size_t o_scr = carve((size_t)stride64 * (size_t)slots + 64), o_z = carve((size_t)zslot * (size_t)slots + 64);
     // pinned: [ReadParams n | DevParams | strand offsets 2n+1 | the int block] ; the dense results are staged in a second pinned buffer
     size_t hsz = 0;
     auto hcarve = [&](size_t bytes) { const size_t at = hsz; hsz += (bytes + 63) & ~(size_t)63; return at; };
@@ -2426,7 +2430,8 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     A.base = pl->d_base.as<int64_t>(); A.reg = pl->d_reg.as<alfa_region>(); A.members = pl->d_rm.as<alfa_match>();
     A.nreg = d_aux + 2 * (size_t)nq; A.rstatus = d_aux + 4 * (size_t)nq;
     A.dp_params = dA + o_prm; A.scratch = (uint8_t*)(dA + o_scr); A.scratch_stride = (int32_t)stride64; A.qcap = qcap;
-    A.zscratch = (uint8_t*)(dA + o_z); A.zstride = zstride;
+    A.zscratch = (uint8_t*)(dA + o_z); A.zstride = zstride; A.zslot = zslot; A.bam_cap = bam_cap;
+    A.slots = slots; A.next = d_int + nints;          // (the int block has 8 spare words behind its arrays; all zeroed below)
     A.opt.cigarCount = o->cigar_alignments > 0 ? o->cigar_alignments : 0; A.opt.pad_ = 0;
     A.opt.match = o->match; A.opt.mismatch = o->mismatch; A.opt.openGap = o->open_gap; A.opt.extendGap = o->extend_gap;
     A.opt.global = o->global; A.opt.fixedBandSize = o->fixed_band; A.opt.maxTrial = o->max_trial; A.opt.maxTrialBest = o->max_trial_best;
