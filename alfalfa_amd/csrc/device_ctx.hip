@@ -164,13 +164,20 @@ int Ctx::ensure(int dev) {
     return ALFA_OK;
 }
 
-// Side streams are made at their first use: a thread that only maps whole reads (alfa_map_reads_batch: one stream) never
-// needs them, and 16 such threads would otherwise hold 224 idle streams -- which HIP's shutdown then takes 0.1 s to destroy.
+// Side streams are made at the first use of any of them, all NSIDE at once and in index order: a thread that only maps whole
+// reads (alfa_map_reads_batch: one stream) never needs them -- 16 such threads would otherwise hold 224 idle streams, which
+// HIP's shutdown then takes 0.1 s to destroy -- and for a thread that does, creation order decides which streams share a
+// hardware queue (HIP deals them out round-robin), which the assignment of kernel bins to side streams was tuned for
+// (ksw_kernels.hip launch_all).
 hipStream_t Ctx::side_stream(int k) {
-    if (!side[k] && hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking) != hipSuccess) {
-        (void)hipGetLastError();
-        side[k] = nullptr;
-        return stream;               // (out of streams: the chain runs on the main stream, in order -- slower, never wrong)
+    if (!side[0]) {
+        for (int j = 0; j < NSIDE; ++j) {
+            if (hipStreamCreateWithFlags(&side[j], hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError();
+                for (int i = 0; i <= j; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); side[i] = nullptr; }
+                return stream;       // (out of streams: the chain runs on the main stream, in order -- slower, never wrong)
+            }
+        }
     }
     return side[k];
 }
