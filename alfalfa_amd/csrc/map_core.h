@@ -37,7 +37,7 @@ constexpr int CHAINOUT_CAP = 96;    // seeds of all reported chains of a read
 constexpr int OPS_CAP = 160;        // extended CIGAR operations of a read's reported alignments: the least a caller provides room for
 constexpr int BAM_CAP = 96;         // BAM CIGAR operations of one ksw_global call
 
-enum Status { DONE = 0, NEED_CALLER = 1 };      // NEED_CALLER: the caller maps this read itself (a capacity was exceeded, the
+enum Status { DONE = 0, NEED_CALLER = 1, NO_SEED = 2, NO_ALIGNMENT = 3 };      // NEED_CALLER: the caller maps this read itself (a capacity was exceeded, the
                                                 // re-seeding rescue is due, a DP task is outside the wave kernel's envelope)
 // An alignment whose extended CIGAR was not made here (it is not among the first `cigarCount` by score, or a capacity was
 // exceeded, or a ksw_global call was degenerate) has opCount = -1: the caller recovers it through ksw_global as before.
@@ -45,7 +45,7 @@ enum Status { DONE = 0, NEED_CALLER = 1 };      // NEED_CALLER: the caller maps 
 struct Options {                    // align_opt (src/options.h), the fields the trial loop reads
     int32_t match, mismatch, openGap, extendGap;     // openGap / extendGap as alnOptions holds them: negative
     int32_t global, fixedBandSize, maxTrial, maxTrialBest, maxAlnCount, rescue;
-    int32_t cigarCount, pad_;       // extended CIGARs for the first cigarCount alignments by score (alignmentCount; 0 = none)
+    int32_t cigarCount, rescueOnly; // rescueOnly: only the looser pass, and no alignment = done (the RESCUE2 round src/mapper.cpp:1290-1300); extended CIGARs for the first cigarCount alignments by score (alignmentCount; 0 = none)
     double errorPercent;
 };
 
@@ -169,7 +169,7 @@ MC_FN bool covers_new_bases(Work& W, int strand, int n) {
         if (!hasLower || tq[ub - 1] + tl[ub - 1] < q + len) {
             if (hasLower && tq[ub - 1] == q) tl[ub - 1] = len;
             else {
-                if (tn >= TREE_CAP) { W.fail = 1; break; }
+                if (tn >= TREE_CAP) { W.fail = 5; break; }
                 for (int j = tn; j > ub; --j) { tq[j] = tq[j - 1]; tl[j] = tl[j - 1]; }
                 tq[ub] = q; tl[ub] = len;
                 ++tn;
@@ -287,7 +287,7 @@ MC_FN int try_region(Env& env, Work& W, const Options& O, const ReadParams& R, i
                 const int wide = d + (int)(d * O.errorPercent);
                 inner = inner > wide ? inner : wide;
                 int s = 0;
-                if (!env.nw(fw, qE + 1, qLen, rE + 1, tLen, inner, s)) { W.fail = 1; return best; }
+                if (!env.nw(fw, qE + 1, qLen, rE + 1, tLen, inner, s)) { W.fail = 6; return best; }
                 score += s;
             }
             rE = sR + sL - 1;
@@ -304,7 +304,7 @@ MC_FN int try_region(Env& env, Work& W, const Options& O, const ReadParams& R, i
                     lo = lo > chrStart ? lo : chrStart;
                     const int tLen = (int)(rB - lo);
                     ExtRes r;
-                    if (!env.extend(fw, true, qB, qB, rB, tLen, band < qB ? band : qB, score, r)) { W.fail = 1; return best; }
+                    if (!env.extend(fw, true, qB, qB, rB, tLen, band < qB ? band : qB, score, r)) { W.fail = 7; return best; }
                     score = r.score;
                     if (O.global || r.gscore >= score + (O.mismatch - O.match) * 3) { score = r.gscore; rB -= r.gtle; qB = 0; }
                     else { qB -= r.qle; rB -= r.tle; }
@@ -316,7 +316,7 @@ MC_FN int try_region(Env& env, Work& W, const Options& O, const ReadParams& R, i
                     hi = hi < chrEnd ? hi : chrEnd;
                     const int tLen = (int)(hi - rE), qLen = plen - 1 - qE;
                     ExtRes r;
-                    if (!env.extend(fw, false, qE, qLen, rE, tLen, band < qLen ? band : qLen, score, r)) { W.fail = 1; return best; }
+                    if (!env.extend(fw, false, qE, qLen, rE, tLen, band < qLen ? band : qLen, score, r)) { W.fail = 7; return best; }
                     score = r.score;
                     if (O.global || r.gscore >= score + (O.mismatch - O.match) * 3) { score = r.gscore; rE += r.gtle; qE = plen - 1; }
                     else { qE += r.qle; rE += r.tle; }
@@ -332,7 +332,7 @@ MC_FN int try_region(Env& env, Work& W, const Options& O, const ReadParams& R, i
                 if (W.accScore[k] >= score && (dd < 0 ? -dd : dd) < editDist) dup = true;
             }
             if (!dup) {
-                if (nAcc >= BOUND_CAP || W.nAln >= ALN_CAP || W.nChainOut + chainLen > CHAINOUT_CAP) { W.fail = 1; return best; }
+                if (nAcc >= BOUND_CAP || W.nAln >= ALN_CAP || W.nChainOut + chainLen > CHAINOUT_CAP) { W.fail = 8; return best; }
                 AlnOut o;
                 o.refB = rB; o.refE = rE; o.qB = qB; o.qE = qE; o.score = score; o.fw = fw ? 1 : 0;
                 o.chainFirst = W.nChainOut; o.chainCount = chainLen; o.opFirst = 0; o.opCount = -1; o.editDist = 0; o.pad_ = 0;
@@ -347,7 +347,7 @@ MC_FN int try_region(Env& env, Work& W, const Options& O, const ReadParams& R, i
                 ++nAcc;
             }
         }
-        if (nBounds >= BOUND_CAP) { W.fail = 1; return best; }
+        if (nBounds >= BOUND_CAP) { W.fail = 9; return best; }
         Trial t; t.refB = rB; t.refE = rE; t.qB = qB; t.qE = qE;
         W.bounds[nBounds++] = t;
     }
@@ -363,7 +363,7 @@ MC_FN void run_regions(Env& env, Work& W, const Options& O, const ReadParams& R,
     for (int li = 0; li < nRegions && W.nAln < maxAln && !W.fail; ++li) {
         int n, score;
         bool fw;
-        if (!env.load_region(W, W.rorder[li], n, fw, score)) { W.fail = 1; return; }
+        if (!env.load_region(W, W.rorder[li], n, fw, score)) { W.fail = 10; return; }
         const int s = fw ? 1 : 0;
         const bool unique = covers_new_bases(W, s, n);
         if (W.fail) return;
@@ -514,17 +514,19 @@ MC_FN void build_cigars(Env& env, Work& W, const Options& O, const ReadParams& R
 template <class Env>
 MC_FN int map_read(Env& env, Work& W, const Options& O, const ReadParams& R, int nRegions) {
     W.nAln = 0; W.nChainOut = 0; W.nOps = 0; W.fail = 0;
-    if (nRegions > REGION_CAP2) return NEED_CALLER;
+    if (nRegions > REGION_CAP2) { W.fail = 3; return NEED_CALLER; }
     for (int k = 0; k < nRegions; ++k) W.rorder[k] = (uint16_t)k;
     const int32_t* sc = W.rscore;
-    if (!sort_like_libstdcxx(W.rorder, nRegions, [sc](uint16_t x, uint16_t y) { return sc[x] > sc[y]; })) return NEED_CALLER;   // compIntervals :1114
+    if (!sort_like_libstdcxx(W.rorder, nRegions, [sc](uint16_t x, uint16_t y) { return sc[x] > sc[y]; })) { W.fail = 4; return NEED_CALLER; }   // compIntervals :1114
     if (nRegions == 0) return DONE;                          // :1272: no regions, no rescue
-    run_regions(env, W, O, R, nRegions, O.maxAlnCount, R.minCoverage, R.minScore);
-    if (W.fail) return NEED_CALLER;
-    if (W.nAln == 0 && O.rescue) {
+    if (!O.rescueOnly) {
+        run_regions(env, W, O, R, nRegions, O.maxAlnCount, R.minCoverage, R.minScore);
+        if (W.fail) return NEED_CALLER;
+    }
+    if (W.nAln == 0 && (O.rescue || O.rescueOnly)) {
         run_regions(env, W, O, R, nRegions, 20, R.minCoverage2, R.minScore2);
         if (W.fail) return NEED_CALLER;
-        if (W.nAln == 0) return NEED_CALLER;                 // the re-seeding rescue (:1290-1300) stays with the caller
+        if (W.nAln == 0 && !O.rescueOnly) { W.fail = 11; return NO_ALIGNMENT; }      // RESCUE2 (:1290-1300) is a call of its own
     }
     if (O.cigarCount > 0) build_cigars(env, W, O, R);
     return DONE;

@@ -234,14 +234,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         const int sf = 2 * r, sr = 2 * r + 1;
         const int64_t bf = A.base[sf], br = A.base[sr], be = A.base[sr + 1];
         int status = mapcore::DONE, naln = 0, nseed = 0, nops = 0;
-        if (A.rstatus[sf] | A.rstatus[sr]) status = mapcore::NEED_CALLER;           // regions_kernel handed a strand back
-        else if (be == bf) status = A.opt.rescue ? mapcore::NEED_CALLER : mapcore::DONE;      // no seed on either strand: the seed rescue rounds (src/mapper.cpp:542-555) stay with the caller
+        // why a read is handed back (A.reasons): 1 regions_kernel handed a strand back, 2 no seed (the caller's seed rescue),
+        // 3 regions > REGION_CAP2, 4 sort depth, 5 TREE_CAP, 6 ksw_nw / 7 ksw_extend call beyond the kernel's band or scratch,
+        // 8 BOUND_CAP / ALN_CAP / CHAINOUT_CAP, 9 BOUND_CAP, 10 region members > MEMBER_CAP, 11 no alignment (re-seeding rescue)
+        int why = 0;
+        if (A.rstatus[sf] | A.rstatus[sr]) { status = mapcore::NEED_CALLER; why = 1; }          // regions_kernel handed a strand back
+        else if (be == bf) { status = (A.opt.rescue || A.opt.rescueOnly) ? mapcore::NO_SEED : mapcore::DONE; why = 2; }      // no seed on either strand: the seed rescue rounds (src/mapper.cpp:542-555) stay with the caller
         else {
             DevEnv env{A, ln, r, slot, A.reads + A.read_off[sf], A.reads + A.read_off[sr], A.scratch + (int64_t)slot * A.scratch_stride, ztile,
                        (const DevParams*)A.dp_params, A.reg + bf, A.reg + br, A.members + 2 * bf + 8 * (int64_t)sf,
                        A.members + 2 * br + 8 * (int64_t)sr, A.nreg[sf], A.nreg[sr]};
             const int nreg = env.nF + env.nR;
-            if (nreg > mapcore::REGION_CAP2) status = mapcore::NEED_CALLER;
+            if (nreg > mapcore::REGION_CAP2) { status = mapcore::NEED_CALLER; why = 3; }
             else {
                 for (int k = ln; k < nreg; k += 64) W.rscore[k] = k < env.nF ? env.regF[k].score : env.regR[k - env.nF].score;
                 W.ops = A.ops + (int64_t)r * A.ops_cap;          // (every lane stores the same values)
@@ -249,6 +253,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 W.bamp = W.bam;
                 __syncthreads();
                 status = mapcore::map_read(env, W, A.opt, A.rp[r], nreg);
+                why = W.fail;
                 if (status == mapcore::DONE) {
                     naln = W.nAln; nseed = W.nChainOut; nops = W.nOps;
                     __syncthreads();
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             }
         }
         if (ln == 0) {
+            if (status != mapcore::DONE) atomicAdd(A.reasons + (why & 15), 1);
             A.status[r] = status;
             A.naln[r] = naln;
             A.nseed[r] = nseed;

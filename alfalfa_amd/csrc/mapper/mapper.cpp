@@ -769,7 +769,7 @@ mapcore::Options core_options(const AlignOpt& o) {
     O.match = o.match; O.mismatch = o.mismatch; O.openGap = o.openGap; O.extendGap = o.extendGap;
     O.global = o.global ? 1 : 0; O.fixedBandSize = o.fixedBandSize; O.maxTrial = o.maxTrial; O.maxTrialBest = o.maxTrialBest ? 1 : 0;
     O.maxAlnCount = o.maxAlnCount; O.rescue = o.rescue ? 1 : 0; O.errorPercent = o.errorPercent;
-    O.cigarCount = o.fullDP ? 0 : o.alignmentCount; O.pad_ = 0;       // --full-dp recomputes whole alignments: no chain CIGARs
+    O.cigarCount = o.fullDP ? 0 : o.alignmentCount; O.rescueOnly = 0;       // --full-dp recomputes whole alignments: no chain CIGARs
     return O;
 }
 
@@ -1068,18 +1068,25 @@ void Mapper::map_options(alfa_map_options& mo) const {
     mo.cigar_alignments = opt_.fullDP ? 0 : opt_.alignmentCount;
 }
 
-void Mapper::describe(const char* P, const char* Prc, int Plength, alfa_map_read& x) const {
+void Mapper::describe(const char* P, const char* Prc, int Plength, alfa_map_read& x, double errorPercent, int memStage) const {
     const int K = (int)idx_.K();
-    const mapcore::ReadParams R = core_read_params(opt_, Plength);
-    // min_len: calculateCandRegions src/mapper.cpp:1225-1231; sparseSkip: calculateSeedsBothStrands :533-536
+    const mapcore::ReadParams R = core_read_params(opt_, Plength);          // the trial loop's thresholds: always from alnOptions.errorPercent (:1280)
+    // calculateCandRegions src/mapper.cpp:1224-1231 with its errorPercent parameter; sparseSkip: calculateSeedsBothStrands :533-536
+    const int editDist = (int)(errorPercent * Plength) + 1;
     int min_len = opt_.minMemLength;
-    if (!opt_.fixedMinLength && Plength >= 1000) min_len += (20 * ((int)(Plength / 500))) / ((int)100 * opt_.errorPercent);
-    if (opt_.fixedMinLength && Plength / R.editDist > min_len) min_len = Plength / R.editDist;
+    if (!opt_.fixedMinLength && Plength >= 1000) min_len += (20 * ((int)(Plength / 500))) / ((int)100 * errorPercent);
+    if (opt_.fixedMinLength && Plength / editDist > min_len) min_len = Plength / editDist;
     int sparseSkip = K >= 4 ? std::max((min_len - 10) / K, 1) : std::max((min_len - 12) / K, 1);
     if (opt_.noSparseQ) sparseSkip = 1;
+    if (memStage) {                                  // MEMRESCUE :542-555 (the call also raises max_seed_candidates to 100000)
+        const int minLength = std::max(MIN_SEED_LENGTH, K + 10);
+        min_len = memStage == 1 ? (minLength + min_len) / 2 : minLength;
+        sparseSkip = 1;
+    }
     x.P = P; x.Prc = Prc; x.plen = Plength;
     x.min_len = min_len; x.sparse_q = sparseSkip;
     x.edit_dist = R.editDist; x.min_score = R.minScore; x.min_coverage = R.minCoverage; x.min_score2 = R.minScore2; x.min_coverage2 = R.minCoverage2;
+    x.region_edit_dist = editDist; x.reserved = 0;
 }
 
 void Mapper::map_call(const alfa_map_options& mo, int n, MapCallResult& R) {
@@ -1105,10 +1112,6 @@ void Mapper::map_call(const alfa_map_options& mo, int n, MapCallResult& R) {
         fprintf(stderr, "ERROR: alfa_map_reads_batch failed (%d): %s\n", rc, hot_.ops().last_error ? hot_.ops().last_error() : "");
         exit(1);
     }
-    long nd = 0;
-    for (int i = 0; i < n; ++i) nd += R.st[(size_t)i] == 0;
-    g_core_done += nd;
-    g_core_fallback += n - nd;
 }
 
 // the call's alignments of read i as alignment_t objects, as unpairedMatch would have left them
@@ -1140,30 +1143,33 @@ void Mapper::map_batch(Read* const* reads, int n, std::vector<uint8_t>& done) {
     map_options(mo);
     const auto tm0 = std::chrono::steady_clock::now();
     rd_.resize((size_t)n);
-    for (int i = 0; i < n; ++i) describe(reads[i]->sequence.data(), reads[i]->rcSequence.data(), (int)reads[i]->sequence.length(), rd_[(size_t)i]);
+    for (int i = 0; i < n; ++i)
+        describe(reads[i]->sequence.data(), reads[i]->rcSequence.data(), (int)reads[i]->sequence.length(), rd_[(size_t)i], opt_.errorPercent);
     g_map_us[0] += (long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tm0).count();
     MapCallResult R;
     map_call(mo, n, R);
     const auto t1 = std::chrono::steady_clock::now();
+    long nd = 0;
     for (int i = 0; i < n; ++i) {
-        if (R.st[(size_t)i] != 0) continue;
+        if (R.st[(size_t)i] != 0) continue;          // (1: a capacity; 2, 3: the rescue rounds -- unpaired_match runs them for these reads)
         adopt(*reads[i], R, i);
         done[(size_t)i] = 1;
+        ++nd;
     }
+    g_core_done += nd;
+    g_core_fallback += n - nd;
     g_map_us[2] += (long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
 }
 
-void Mapper::map_raw(const RawRead* raw, int n, MapCallResult& R) {
-    if (n <= 0) { R.st.clear(); R.aoff.assign(1, 0); R.soff.assign(1, 0); R.ooff.assign(1, 0); return; }
-    alfa_map_options mo;
-    map_options(mo);
+void Mapper::map_raw(const RawRead* raw, int n, std::vector<std::unique_ptr<MapCallResult>>& calls, std::vector<RawResult>& res) {
+    res.assign((size_t)n, RawResult());
+    if (n <= 0) return;
     const auto tm0 = std::chrono::steady_clock::now();
     strandOff_.resize((size_t)n);
     rawLen_.resize((size_t)n);
     size_t total = 0;
     for (int i = 0; i < n; ++i) { strandOff_[(size_t)i] = total; rawLen_[(size_t)i] = raw[i].len; total += 2 * (size_t)raw[i].len; }
     if (strands_.size() < total) strands_.resize(total);
-    rd_.resize((size_t)n);
     for (int i = 0; i < n; ++i) {
         const int len = raw[i].len;
         char* fw = &strands_[strandOff_[(size_t)i]];
@@ -1174,17 +1180,63 @@ void Mapper::map_raw(const RawRead* raw, int n, MapCallResult& R) {
             fw[k] = (char)c;
             rc[len - 1 - k] = RC.t[c];
         }
-        describe(fw, rc, len, rd_[(size_t)i]);
     }
     g_map_us[0] += (long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tm0).count();
-    map_call(mo, n, R);
+    // The rounds of unpairedMatch (src/mapper.cpp:1269-1302), each a call for the reads that reach it:
+    //   A      calculateCandRegions(errorPercent), both passes
+    //   M1, M2 the same after the seed rescue's first / second round (no seed at all in the round before, :542-555)
+    //   R2     RESCUE2: calculateCandRegions(2 x errorPercent), the looser pass only (no alignment in A / M1 / M2, :1290-1300)
+    //   R2M1, R2M2  the seed rescue inside RESCUE2's calculateCandRegions
+    // A read that has no seed after the last seed round, or no alignment after RESCUE2, is unmapped.
+    enum { S_A, S_M1, S_M2, S_R2, S_R2M1, S_R2M2, S_COUNT };
+    std::vector<int> pending[S_COUNT];
+    pending[S_A].resize((size_t)n);
+    for (int i = 0; i < n; ++i) pending[S_A][(size_t)i] = i;
+    for (int state = S_A; state < S_COUNT; ++state) {
+        const std::vector<int>& who = pending[state];
+        if (who.empty()) continue;
+        alfa_map_options mo;
+        map_options(mo);
+        const bool r2 = state >= S_R2;
+        const int memStage = (state == S_M1 || state == S_R2M1) ? 1 : (state == S_M2 || state == S_R2M2) ? 2 : 0;
+        if (r2) mo.rescue_only = 1;
+        if (memStage) mo.max_seed_candidates = 100000;
+        const auto td0 = std::chrono::steady_clock::now();
+        rd_.resize(who.size());
+        for (size_t k = 0; k < who.size(); ++k) {
+            const int i = who[k];
+            describe(strand(i, false), strand(i, true), raw[i].len, rd_[k], r2 ? 2.0 * opt_.errorPercent : opt_.errorPercent, memStage);
+        }
+        g_map_us[0] += (long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - td0).count();
+        calls.emplace_back(new MapCallResult());
+        MapCallResult& R = *calls.back();
+        map_call(mo, (int)who.size(), R);
+        for (size_t k = 0; k < who.size(); ++k) {
+            const int i = who[k];
+            res[(size_t)i] = RawResult{&R, (int)k, false};
+            const int st = R.st[k];
+            int next = -2;                                         // -2: final as it is
+            if (st == ALFA_MAP_NO_SEED)
+                next = state == S_A ? S_M1 : state == S_M1 ? S_M2 : state == S_R2 ? S_R2M1 : state == S_R2M1 ? S_R2M2 : -1;
+            else if (st == ALFA_MAP_NO_ALIGNMENT) next = r2 ? -1 : S_R2;
+            if (next == -1) res[(size_t)i].unmapped = true;
+            else if (next >= 0) pending[next].push_back(i);
+        }
+    }
+    long nd = 0;
+    for (int i = 0; i < n; ++i) nd += device_done(res[(size_t)i]);
+    g_core_done += nd;
+    g_core_fallback += n - nd;
 }
 
 // a read the device finished, with no alignment or with exactly one that brought its CIGAR along, and one alignment to print
-bool Mapper::direct_ok(const MapCallResult& R, int i) const {
-    if (R.st[(size_t)i] != 0 || opt_.fullDP || opt_.alignmentCount < 1) return false;
-    const int64_t na = R.aoff[(size_t)i + 1] - R.aoff[(size_t)i];
-    return na == 0 || (na == 1 && R.al[R.aoff[(size_t)i]].op_count >= 0);
+bool Mapper::direct_ok(const RawResult& rs) const {
+    if (rs.unmapped) return true;
+    const MapCallResult& R = *rs.R;
+    const size_t i = (size_t)rs.j;
+    if (R.st[i] != 0 || opt_.fullDP || opt_.alignmentCount < 1) return false;
+    const int64_t na = R.aoff[i + 1] - R.aoff[i];
+    return na == 0 || (na == 1 && R.al[R.aoff[i]].op_count >= 0);
 }
 
 namespace {
@@ -1194,10 +1246,12 @@ inline char* put_int(char* p, long v) {
 }
 }  // namespace
 
-void Mapper::render_direct(const RawRead& rr, int i, const MapCallResult& R, std::string& out, long* mappedPrinted) {
+void Mapper::render_direct(const RawRead& rr, int i, const RawResult& rs, std::string& out, long* mappedPrinted) {
     const int len = rr.len;
     const size_t at = out.size();
-    if (R.aoff[(size_t)i + 1] == R.aoff[(size_t)i]) {          // read_t::emptyAlingment src/mapper.h:170-179, unpaired
+    const MapCallResult& R = *rs.R;
+    const size_t j = (size_t)rs.j;
+    if (rs.unmapped || R.aoff[j + 1] == R.aoff[j]) {          // read_t::emptyAlingment src/mapper.h:170-179, unpaired
         out.resize(at + (size_t)rr.nameLen + 2 * (size_t)len + 32);
         char* p = &out[at];
         memcpy(p, rr.name, (size_t)rr.nameLen); p += rr.nameLen;
@@ -1210,8 +1264,8 @@ void Mapper::render_direct(const RawRead& rr, int i, const MapCallResult& R, std
         out.resize((size_t)(p - out.data()));
         return;
     }
-    const alfa_map_alignment& a = R.al[R.aoff[(size_t)i]];
-    const alfa_map_cigar_op* ops = R.op + R.ooff[(size_t)i] + a.op_first;
+    const alfa_map_alignment& a = R.al[R.aoff[j]];
+    const alfa_map_cigar_op* ops = R.op + R.ooff[j] + a.op_first;
     const int nops = a.op_count;
     const bool rc = !a.forward;
     // setLocalPos src/mapper.h:104-112

@@ -5,6 +5,7 @@
 // behaviour it reproduces.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -119,6 +120,9 @@ struct MapCallResult {
     ~MapCallResult() { if (free_fn) { free_fn(al); free_fn(sd); free_fn(op); } }
 };
 
+// where a read's final result lies after map_raw's rounds: entry j of one of the calls, or nowhere (unmapped after the last round)
+struct RawResult { const MapCallResult* R = nullptr; int j = 0; bool unmapped = false; };
+
 struct RefIndex {                 // the parts of `sparseSA` the mapper itself touches
     const alfa_host_index* h = nullptr;
     const alfa_index_view* v = nullptr;
@@ -143,14 +147,17 @@ class Mapper {
     bool device_map_usable() const;
     void map_batch(Read* const* reads, int n, std::vector<uint8_t>& done);
     // ---- the same for records the reader only split: map_raw() lower-cases every read and its reverse complement into one
-    // buffer (strand(i, rc)) and makes the call; a read the device finished with at most one alignment, CIGAR included, -- nearly
-    // all short reads -- then goes from the call's results straight to its SAM line (render_direct: read_t::postprocess
-    // src/mapper.cpp:322-358 and printUnpairedAlignment src/mapper.h:181-193 for that case, no read_t / alignment_t objects in
-    // between); every other read is materialised and takes the general path (adopt() gives it the call's alignments)
-    void map_raw(const RawRead* raw, int n, MapCallResult& R);
+    // buffer (strand(i, rc)) and makes the call -- and then the reference's rescue rounds as further calls for the reads that
+    // need them (unpairedMatch src/mapper.cpp:1290-1300 RESCUE2, calculateSeedsBothStrands :542-555 MEMRESCUE): res[i] says
+    // where read i's final result lies.  A read the device finished with at most one alignment, CIGAR included, -- nearly all
+    // reads -- then goes from there straight to its SAM line (render_direct: read_t::postprocess src/mapper.cpp:322-358 and
+    // printUnpairedAlignment src/mapper.h:181-193 for that case, no read_t / alignment_t objects in between); every other
+    // read is materialised and takes the general path (adopt() gives it the call's alignments when it has them)
+    void map_raw(const RawRead* raw, int n, std::vector<std::unique_ptr<MapCallResult>>& calls, std::vector<RawResult>& res);
     const char* strand(int i, bool rc) const { return strands_.data() + strandOff_[(size_t)i] + (rc ? rawLen_[(size_t)i] : 0); }
-    bool direct_ok(const MapCallResult& R, int i) const;
-    void render_direct(const RawRead& rr, int i, const MapCallResult& R, std::string& out, long* mappedPrinted);
+    bool direct_ok(const RawResult& rs) const;
+    bool device_done(const RawResult& rs) const { return rs.unmapped || rs.R->st[(size_t)rs.j] == 0; }
+    void render_direct(const RawRead& rr, int i, const RawResult& rs, std::string& out, long* mappedPrinted);
     void adopt(Read& r, const MapCallResult& R, int i);
     void map_unpaired_rest(Read& read, bool done);      // what is left of map_unpaired after map_batch: (unpaired_match,) postprocess
     bool finish_unpaired_direct(Read& read);            // ... for a read whose CIGARs came with its alignments: no fiber needed; false = needs one
@@ -206,7 +213,9 @@ class Mapper {
     void set_paired(Read& m1, Read& m2, int i, int j, bool concordant);
     bool is_concordant(const Alignment& a, const Alignment& b) const;
     void map_options(alfa_map_options& mo) const;
-    void describe(const char* P, const char* Prc, int Plength, alfa_map_read& x) const;
+    // the per-read record of a call; errorPercent and memStage select the round (calculateCandRegions' parameter, :1224-1231; the
+    // seed rescue's stage 0 / 1 / 2, :542-555)
+    void describe(const char* P, const char* Prc, int Plength, alfa_map_read& x, double errorPercent, int memStage = 0) const;
     void map_call(const alfa_map_options& mo, int n, MapCallResult& R);      // rd_[0..n) described
     const RefIndex& idx_;
     const AlignOpt& opt_;

@@ -624,23 +624,25 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                     static thread_local std::vector<RawRead> raw;
                     raw.resize((size_t)n);
                     for (int i = 0; i < n; i++) raw[(size_t)i] = raw_read(B.ra[lo + i]);
-                    MapCallResult R;
+                    std::vector<std::unique_ptr<MapCallResult>> calls;
+                    std::vector<RawResult> res;
                     const double td0 = now();
-                    mp.map_raw(raw.data(), n, R);
+                    mp.map_raw(raw.data(), n, calls, res);
                     const double td1 = now();
                     w_dev[t] += td1 - td0;
                     std::vector<uint8_t> direct((size_t)n);
                     std::vector<int> rest;
+                    std::vector<uint8_t> done((size_t)n);
                     for (int i = 0; i < n; i++) {
-                        if ((direct[(size_t)i] = mp.direct_ok(R, i))) continue;
+                        if ((direct[(size_t)i] = mp.direct_ok(res[(size_t)i]))) continue;
                         Read& r = B.a[lo + i];
                         materialize(B.ra[lo + i], r);
                         r.init();
-                        const bool done = R.st[(size_t)i] == 0;
-                        if (done) mp.adopt(r, R, i);
-                        if (!(done && mp.finish_unpaired_direct(r))) rest.push_back(i);
+                        done[(size_t)i] = mp.device_done(res[(size_t)i]);
+                        if (done[(size_t)i]) mp.adopt(r, *res[(size_t)i].R, res[(size_t)i].j);
+                        if (!(done[(size_t)i] && mp.finish_unpaired_direct(r))) rest.push_back(i);
                     }
-                    scheds[t]->run((int)rest.size(), o.fibers, [&](int k) { mp.map_unpaired_rest(B.a[lo + rest[(size_t)k]], R.st[(size_t)rest[(size_t)k]] == 0); });
+                    scheds[t]->run((int)rest.size(), o.fibers, [&](int k) { mp.map_unpaired_rest(B.a[lo + rest[(size_t)k]], done[(size_t)rest[(size_t)k]] != 0); });
                     const double tb2 = now();
                     w_build[t] += td0 - tb0; w_run[t] += tb2 - td0;
                     size_t bytes = 0;
@@ -650,7 +652,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                     for (int i = 0; i < n; i++) {
                         if (direct[(size_t)i]) {
                             const long before = c[0];
-                            mp.render_direct(raw[(size_t)i], i, R, txt, c);
+                            mp.render_direct(raw[(size_t)i], i, res[(size_t)i], txt, c);
                             with_cigar += c[0] - before;
                             continue;
                         }

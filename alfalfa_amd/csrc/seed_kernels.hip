@@ -2348,7 +2348,7 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
         (rc = pl->d_chain.reserve(4 * (rm_slots + 1))) || (rc = pl->d_aux.reserve(4 * 5 * (size_t)nq + 64)) || (rc = cx->h_tasks.reserve(4 * 5 * (size_t)nq + 64)))
         return rc;
     int32_t* h_aux = cx->h_tasks.as<int32_t>();                 // [qlen | edit | nreg | nrm | status]
-    for (int i = 0; i < nq; ++i) { h_aux[i] = reads[i >> 1].plen; h_aux[nq + i] = reads[i >> 1].edit_dist; }
+    for (int i = 0; i < nq; ++i) { const alfa_map_read& r = reads[i >> 1]; h_aux[i] = r.plen; h_aux[nq + i] = r.region_edit_dist > 0 ? r.region_edit_dist : r.edit_dist; }
     int32_t* d_aux = pl->d_aux.as<int32_t>();
     ALFA_HIP(hipMemcpyAsync(d_aux, h_aux, 4 * 2 * (size_t)nq, hipMemcpyHostToDevice, st));
     alfa::RegionParams rp;
@@ -2366,7 +2366,7 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     const int qcap = (max_plen + 15) & ~15;
     const int64_t stride64 = (16 + (int64_t)qcap + 16 + (int64_t)max_plen + max_edit + 64 + 255) & ~(int64_t)255;
     if (stride64 > (1 << 30)) return alfa::fail(ALFA_EINVAL, "read too long for the mapping kernel's scratch");
-    const size_t nints = (size_t)n + 6 * ((size_t)n + 1);              // status[n] | naln | nseed | nops | aln_off | seed_off | op_off, n+1 each (int32)
+    const size_t nints = (size_t)n + 6 * ((size_t)n + 1) + 16;        // (+ 16 words of diagnostics: A.reasons)              // status[n] | naln | nseed | nops | aln_off | seed_off | op_off, n+1 each (int32)
     // scratch of a read in flight, per workgroup of the launch: its staged strings, the direction bytes of its ksw_global call
     // (the whole read at 256 bytes per row: every piece fits) and the BAM operations of that call's walk.  The launch has as
     // many workgroups as the GPU keeps resident -- fewer when the slots would exceed 4 GiB (reads beyond ~5 kbp)
@@ -2431,8 +2431,8 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     A.nreg = d_aux + 2 * (size_t)nq; A.rstatus = d_aux + 4 * (size_t)nq;
     A.dp_params = dA + o_prm; A.scratch = (uint8_t*)(dA + o_scr); A.scratch_stride = (int32_t)stride64; A.qcap = qcap;
     A.zscratch = (uint8_t*)(dA + o_z); A.zstride = zstride; A.zslot = zslot; A.bam_cap = bam_cap;
-    A.slots = slots; A.next = d_int + nints;          // (the int block has 8 spare words behind its arrays; all zeroed below)
-    A.opt.cigarCount = o->cigar_alignments > 0 ? o->cigar_alignments : 0; A.opt.pad_ = 0;
+    A.slots = slots; A.next = d_int + nints; A.reasons = d_int + nints - 16;          // (the int block has 8 spare words behind its arrays; all zeroed below)
+    A.opt.cigarCount = o->cigar_alignments > 0 ? o->cigar_alignments : 0; A.opt.rescueOnly = o->rescue_only ? 1 : 0;
     A.opt.match = o->match; A.opt.mismatch = o->mismatch; A.opt.openGap = o->open_gap; A.opt.extendGap = o->extend_gap;
     A.opt.global = o->global; A.opt.fixedBandSize = o->fixed_band; A.opt.maxTrial = o->max_trial; A.opt.maxTrialBest = o->max_trial_best;
     A.opt.maxAlnCount = o->max_aln_count; A.opt.rescue = o->rescue; A.opt.errorPercent = o->error_percent;
@@ -2487,6 +2487,13 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     alfa::g_last_timing.kernel_ms = ms;
     alfa::g_last_timing.work_units = n;
     alfa::g_last_timing.launches = 1;
+    if (call_log)
+    {
+        const int32_t* why = h_int + nints - 16;
+        fprintf(stderr, "#MAPWHY handed back by cause 1..11:");
+        for (int k = 1; k <= 11; ++k) fprintf(stderr, " %d", why[k]);
+        fprintf(stderr, "\n");
+    }
     if (call_log)
         fprintf(stderr, "#MAPCALL reads %d matches %lld alns %lld fill_ms %.3f seeds_ms %.3f enqueue_ms %.3f regions_map_wait_ms %.3f total_ms %.3f map_kernel_ms %.3f seed_kernel_ms %.3f\n",
                 n, (long long)total, (long long)ta, ms_fill, ms_seeds, ms_enq, ms_map, since(tc0), ms, alfa_seed_plan_kernel_ms(pl));

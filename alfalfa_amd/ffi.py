@@ -583,13 +583,14 @@ class MapOptions(C.Structure):
                 ("global_", C.c_int32), ("fixed_band", C.c_int32), ("max_trial", C.c_int32), ("max_trial_best", C.c_int32),
                 ("max_aln_count", C.c_int32), ("rescue", C.c_int32),
                 ("mem_type", C.c_int32), ("max_seed_candidates", C.c_int32), ("max_smem_start", C.c_int32), ("max_region_mems", C.c_int32),
-                ("min_mem_reg_length", C.c_int32), ("cigar_alignments", C.c_int32), ("error_percent", C.c_double)]
+                ("min_mem_reg_length", C.c_int32), ("cigar_alignments", C.c_int32), ("rescue_only", C.c_int32), ("reserved", C.c_int32),
+                ("error_percent", C.c_double)]
 
 
 class MapRead(C.Structure):
     _fields_ = [("P", C.c_char_p), ("Prc", C.c_char_p), ("plen", C.c_int32), ("min_len", C.c_int32), ("sparse_q", C.c_int32),
                 ("edit_dist", C.c_int32), ("min_score", C.c_int32), ("min_coverage", C.c_int32), ("min_score2", C.c_int32),
-                ("min_coverage2", C.c_int32)]
+                ("min_coverage2", C.c_int32), ("region_edit_dist", C.c_int32), ("reserved", C.c_int32)]
 
 
 MAP_ALN_DTYPE = np.dtype([("ref_begin", "<i8"), ("ref_end", "<i8"), ("q_begin", "<i4"), ("q_end", "<i4"), ("score", "<i4"),

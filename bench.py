@@ -306,7 +306,7 @@ def dist_selftest(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=["c3", "c4"], help="BASELINE configs[2] (default) or configs[3]")
     ap.add_argument("--batch", type=int, default=0, help="reads per step per GPU (default 100000 for c3, 4000 for c4)")
@@ -349,7 +349,7 @@ def main():
     if not c4 and not args.no_c4 and world == 1 and not args.dist_selftest:
         import subprocess
         try:
-            cmd = [sys.executable, os.path.abspath(__file__), "--config", "c4", "--steps", "10", "--warmup", "2", "--align-tasks", "0"]
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", "c4", "--steps", "25", "--warmup", "2", "--align-tasks", "0"]
             if args.no_cpu_baseline:
                 cmd.append("--no-cpu-baseline")
             cenv = dict(os.environ)
@@ -635,9 +635,13 @@ def main():
         erng = np.random.default_rng(77)
         fq = os.path.join(workdir, "e2e.fq")
         open(fq, "wb").close()
+        # N > 1: the reads of ONE GPU's share (steps x batch) are simulated once and written N times (names r<copy>_<i>): the
+        # simulator, not the mapper, would otherwise dominate the run; the mapper keeps nothing from read to read
+        copies = world if (world > 1 and args.e2e_reads == args.steps * args.batch * world) else 1
+        share = args.e2e_reads // copies
         done_reads = 0
-        while done_reads < args.e2e_reads:               # in chunks: the simulator holds a float per base
-            nchunk = min(200000 if not c4 else 20000, args.e2e_reads - done_reads)
+        while done_reads < share:               # in chunks: the simulator holds a float per base
+            nchunk = min(200000 if not c4 else 20000, share - done_reads)
             if c4:
                 er, _ = simulate_long(erng, ref_bytes, nchunk, 2000, 10000, args.err)
             else:
@@ -647,6 +651,12 @@ def main():
                     f.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (done_reads + lo + i, r, b"I" * len(r)) for i, r in enumerate(er[lo:lo + 50000])))
             done_reads += nchunk
             del er
+        if copies > 1:
+            block = open(fq, "rb").read()
+            with open(fq, "ab") as f:
+                for c in range(1, copies):
+                    f.write(block.replace(b"@r", b"@r%d_" % c))
+            del block
         e2e = {"reads": args.e2e_reads, "threads": args.e2e_threads, "gpus": world}
         if world > 1:
             dist.barrier(group=cpu_group)                 # every other rank has released its GPU
@@ -898,14 +908,20 @@ def c4_end_to_end(world, threads, dev):
     pre = os.path.join(wd, "idx")
     hidx.save(pre)
     del hidx
-    n = 20000 * world
+    share = 50000                     # reads per GPU: simulated once, written `world` times (names r<copy>_<i>)
+    n = share * world
     fq = os.path.join(wd, "c4.fq")
     open(fq, "wb").close()
     rng = np.random.default_rng(78)
-    for lo in range(0, n, 20000):
-        er, _ = simulate_long(rng, refb, min(20000, n - lo), 2000, 10000, 0.10)
+    for lo in range(0, share, 10000):
+        er, _ = simulate_long(rng, refb, min(10000, share - lo), 2000, 10000, 0.10)
         with open(fq, "ab") as f:
             f.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (lo + i, r, b"I" * len(r)) for i, r in enumerate(er)))
+    block = open(fq, "rb").read()
+    with open(fq, "ab") as f:
+        for c in range(1, world):
+            f.write(block.replace(b"@r", b"@r%d_" % c))
+    del block
     exe = os.path.join(ROOT, "alfalfa_amd", "alfalfa_amd")
     dt, rcode, err_txt, busy = run_cli(exe, pre, fq, os.path.join(wd, "c4.sam"), threads, ["-e", "0.12"], gpus=world, stats=True)
     md5_all, nrec = sam_record_md5(os.path.join(wd, "c4.sam"))

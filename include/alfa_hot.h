@@ -154,10 +154,19 @@ int  alfa_seed_regions_batch(alfa_index*, int mem_type, const alfa_seed_query* q
  *                   (*alns)[aln_off[i] .. aln_off[i+1]); alignment a's chain (the seeds constructCIGAR walks, :172-271) is
  *                   (*seeds)[seed_off[i] + a.chain_first .. + a.chain_count).  No alignments = the reference finds none
  *                   without re-seeding either (possible only with rescue == 0, or when the read has seeds but no region).
- *   status[i] == 1: the caller maps read i itself through the entry points above (what the reference does next is the
- *                   re-seeding rescue, :542-555 or :1290-1300; or a capacity of the kernel was exceeded: more than 160 seeds
- *                   in a region, 128 regions, 8 alignments or 24 chains per region, a band beyond 256 diagonals; or a strand
- *                   alfa_seed_regions_batch would hand back).  Results are then empty for that read.
+ *   status[i] == 1: the caller maps read i itself through the entry points above (a capacity of the kernel was exceeded:
+ *                   more than 160 seeds in a region, 128 regions, 8 alignments or 24 chains per region, a band beyond 256
+ *                   diagonals; or a strand alfa_seed_regions_batch would hand back).  Results are then empty for that read.
+ *   status[i] == 2: (only with rescue != 0) no seed on either strand.  The reference's next step is the seed rescue
+ *                   (calculateSeedsBothStrands :542-555): the caller makes the same call for these reads with that round's
+ *                   seed parameters (min_len = (max(20, K + 10) + min_len) / 2, then max(20, K + 10); sparse_q = 1,
+ *                   max_seed_candidates = 100000); after the last round the read is unmapped.
+ *   status[i] == 3: (only with rescue != 0) seeds and regions, but no alignment after both passes.  The reference's next
+ *                   step is RESCUE2 (:1290-1300): calculateCandRegions with twice the error rate and only the looser pass --
+ *                   the same call with rescue_only = 1, min_len / sparse_q from 2 x errorPercent and region_edit_dist =
+ *                   (int)(2 x errorPercent x plen) + 1 (edit_dist and the thresholds stay as they were, :1280).  With
+ *                   rescue_only a read without alignment is done (status 0): the reference gives up there as well.
+ *                   (alfalfa_amd align runs these rounds as further calls of this entry point: csrc/mapper/mapper.cpp map_raw.)
  * The float arithmetic that depends only on the read length stays on the host and arrives per read (alfa_map_read), so
  * that the device never rounds differently from the reference.  aln_off, seed_off: n+1 entries, status: n (caller-allocated);
  * *alns and *seeds are library-allocated (alfa_free).  dp: the parameters the mapper passes to ksw_extend / ksw_nw. */
@@ -166,6 +175,8 @@ typedef struct {
     int32_t global, fixed_band, max_trial, max_trial_best, max_aln_count, rescue;
     int32_t mem_type, max_seed_candidates, max_smem_start, max_region_mems, min_mem_reg_length;
     int32_t cigar_alignments;           /* alnOptions.alignmentCount: extended CIGARs for that many alignments per read (0 = none) */
+    int32_t rescue_only;                /* 1: only the looser second pass (:1295-1298), a read without alignment is done -- the RESCUE2 round */
+    int32_t reserved;
     double error_percent;
 } alfa_map_options;
 typedef struct {
@@ -175,7 +186,10 @@ typedef struct {
     int32_t edit_dist;                  /* (int)(errorPercent * plen) + 1                                   :1224 */
     int32_t min_score, min_coverage;    /* first pass                                                        :1281, :1282 */
     int32_t min_score2, min_coverage2;  /* second pass (looser thresholds, at most 20 alignments)            :1285-1287 */
+    int32_t region_edit_dist;           /* identifyAndFilter's editDist when it differs from edit_dist (RESCUE2: :1293 -> :1224); 0 = edit_dist */
+    int32_t reserved;
 } alfa_map_read;
+enum { ALFA_MAP_DONE = 0, ALFA_MAP_CALLER = 1, ALFA_MAP_NO_SEED = 2, ALFA_MAP_NO_ALIGNMENT = 3 };
 typedef struct {
     int64_t ref_begin, ref_end; int32_t q_begin, q_end, score, forward, chain_first, chain_count;
     int32_t op_first, op_count, edit_dist, reserved;   /* the extended CIGAR, when it was made with the alignment: see below */

@@ -48,7 +48,7 @@ def _check_batch(ref, fw, rc, opt, res, want_done=0.99):
     assert len(st) == n and aoff[0] == 0 and soff[0] == 0 and ooff[0] == 0
     assert np.all(np.diff(aoff) >= 0) and np.all(np.diff(soff) >= 0) and np.all(np.diff(ooff) >= 0)
     assert aoff[-1] == len(al) and soff[-1] == len(sd) and ooff[-1] == len(ops)
-    assert set(np.unique(st)) <= {0, 1}
+    assert set(np.unique(st)) <= {0, 1, 2, 3}                       # 2, 3: the rescue rounds are further calls (alfa_hot.h)
     assert (st == 0).mean() >= want_done
     handed = np.nonzero(st != 0)[0]
     assert np.all(aoff[handed + 1] == aoff[handed])                 # a read that is handed back brings nothing
@@ -151,7 +151,23 @@ def test_map_batch_edge_cases(c3):
     res = ffi.map_reads_batch(didx, opt, P, ffi.make_map_reads(reads_fw, reads_rc, 12, opt))
     st, aoff, al, soff, sd, ooff, ops = res
     assert st[0] == 0 and aoff[1] - aoff[0] == 1 and al[0]["ref_begin"] == 1000000 and al[0]["score"] == 250 and al[0]["forward"] == 1
-    assert st[1] == 1 and st[2] == 1                                # no seeds: the seed rescue rounds are the caller's
+    assert st[1] == 2 and st[2] == 2                                # no seed: the seed rescue rounds are further calls
+    # ... the last of which (min_len = max(20, K + 10), every position, 100000 candidates) still finds none for the n read
+    optm = ffi.default_map_options()
+    optm.max_seed_candidates = 100000
+    rm = ffi.make_map_reads(reads_fw[1:2], reads_rc[1:2], 12, optm)
+    rm[0].min_len, rm[0].sparse_q = max(20, 12 + 10), 1
+    assert ffi.map_reads_batch(didx, optm, P, rm)[0][0] == 2
+    # RESCUE2's call on a read that maps anyway: only the looser pass runs, the same alignment comes out; a read without
+    # alignment is done there (status 0, nothing)
+    optr = ffi.default_map_options()
+    optr.rescue_only = 1
+    rr = ffi.make_map_reads(reads_fw, reads_rc, 12, optr)
+    for x in rr:
+        x.region_edit_dist = int(2 * optr.error_percent * x.plen) + 1
+    r2 = ffi.map_reads_batch(didx, optr, P, rr)
+    assert r2[0][0] == 0 and r2[2][0]["ref_begin"] == 1000000 and r2[2][0]["score"] == 250
+    assert set(np.unique(r2[0])) <= {0, 1, 2}
     assert st[5] == 0 and aoff[6] - aoff[5] == 1 and al[aoff[5]]["score"] == 250 - 10 * 2          # n against the text: -1 each instead of +1
     # without rescue a seedless read is simply unmapped
     opt2 = ffi.default_map_options()
