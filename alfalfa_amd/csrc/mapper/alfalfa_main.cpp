@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <ctime>
 #include <malloc.h>
+#include <unistd.h>
 
 #include "mapper_cli.h"
 

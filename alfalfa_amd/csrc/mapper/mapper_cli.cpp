@@ -220,7 +220,9 @@ class ReadSource {
     // the memory the last record returned by next() lies in (gzip input); null for a memory-mapped file
     const Chunk& chunk() const { return cur_; }
     // 0: end of input; 1: x describes a record (r untouched); 2: r filled by the general parser (x.p == nullptr)
-    int next(Read& r, RawRec& x) {
+    // (get() yields the Read to fill; it is only called on the general parser's path)
+    template <class GetRead>
+    int next(GetRead&& get, RawRec& x) {
         while (fast_) {
             if (pos_ >= end_ && final_) return 0;
             if (pos_ < end_ && split(x)) return 1;
@@ -231,7 +233,7 @@ class ReadSource {
             slow_.open_mem(base_ + pos_, end_ - pos_);
         }
         x.p = nullptr;
-        return next_read(slow_, r) ? 2 : 0;
+        return next_read(slow_, get()) ? 2 : 0;
     }
    private:
     // a new chunk: the unconsumed tail of the current one, then inflated input until the chunk is full (all: until the end)
@@ -487,7 +489,16 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     const bool direct_render = getenv("ALFA_NO_DIRECT_RENDER") == nullptr;       // (the general path for every read: A/B runs and tests)
 
     struct Batch {
-        std::vector<Read> a, b;               // b stays empty for single-end input; objects beyond n are spares of earlier batches
+        // read objects by position in the batch, made at first use: a read that goes from the split record to the device and from
+        // the call's results to its SAM line never has one (b stays empty for single-end input; the objects stay with the batch
+        // and are used again by later reads at the same position).  Workers touch disjoint positions.
+        struct Slots {
+            std::vector<std::unique_ptr<Read>> v;
+            size_t size() const { return v.size(); }
+            void emplace_back() { v.emplace_back(); }
+            Read& operator[](size_t i) { if (!v[i]) v[i].reset(new Read()); return *v[i]; }
+        };
+        Slots a, b;
         std::vector<RawRec> ra, rb;           // records the reader thread only split: the workers materialise them
         std::vector<ReadSource::Chunk> keep;  // gzip input: the inflated chunks those records lie in
         int n = 0;                            // reads (pairs) of this batch
@@ -601,11 +612,10 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 int64_t cur = 0;
                 while (cur < bpCount && (size_t)B.n < readCap) {
                     if ((int)B.a.size() <= B.n) { B.a.emplace_back(); B.ra.emplace_back(); }
-                    Read& r = B.a[B.n];
-                    const int got = rd.next(r, B.ra[B.n]);
+                    const int got = rd.next([&]() -> Read& { return B.a[(size_t)B.n]; }, B.ra[B.n]);
                     if (got == 1 && rd.chunk() && (B.keep.empty() || B.keep.back() != rd.chunk())) B.keep.push_back(rd.chunk());
                     if (!got) break;
-                    cur += got == 1 ? (int64_t)B.ra[B.n].l2 : (int64_t)r.sequence.length();
+                    cur += got == 1 ? (int64_t)B.ra[B.n].l2 : (int64_t)B.a[(size_t)B.n].sequence.length();
                     B.n++;
                 }
                 return B.n > 0;
@@ -717,8 +727,8 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                     if ((int)B.a.size() <= B.n) { B.a.emplace_back(); B.b.emplace_back(); B.ra.emplace_back(); B.rb.emplace_back(); }
                     Read& a = B.a[B.n];
                     Read& b = B.b[B.n];
-                    const int ok1 = r1.next(a, B.ra[B.n]);
-                    const int ok2 = r2.next(b, B.rb[B.n]);     // the reference keeps only the second status (src/main.cpp:157-158)
+                    const int ok1 = r1.next([&]() -> Read& { return a; }, B.ra[B.n]);
+                    const int ok2 = r2.next([&]() -> Read& { return b; }, B.rb[B.n]);     // the reference keeps only the second status (src/main.cpp:157-158)
                     for (ReadSource* rs : {&r1, &r2})
                         if (rs->chunk() && std::find(B.keep.begin(), B.keep.end(), rs->chunk()) == B.keep.end()) B.keep.push_back(rs->chunk());
                     if (!ok1) {
