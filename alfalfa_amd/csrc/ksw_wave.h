@@ -104,7 +104,10 @@ __device__ __forceinline__ void chain_priority(int rows) {
 // results are wave-uniform and come back through `eo` (ksw_extend) / `score_out` (ksw_nw, ksw_global)
 // ZCOMPACT (ksw_global): rows of direction bytes are `zstride` bytes apart (a multiple of C, > 2w + 1) instead of 64 * C, and only
 // the lanes inside a row store -- a short task's matrix then fits a few KB of LDS (map_kernels.hip)
-template <int MODE, int C, bool PACK = false, bool ZCOMPACT = false>
+// ZEQ (ksw_global): bit 6 of a cell's direction byte says whether the cell's two residues are equal (same nt4 code) -- the
+// walk of map_kernels.hip then writes '=' / 'X' runs directly instead of comparing read and text again (the walk's two-bit
+// fields are bits 0-1, 2-3 and 4-5; bits 3 and 4 stay clear)
+template <int MODE, int C, bool PACK = false, bool ZCOMPACT = false, bool ZEQ = false>
 __device__ __forceinline__ void wave_task_run(const DevTask T, const uint8_t* __restrict__ seq, const DevParams* __restrict__ prm,
                                               uint8_t* __restrict__ zbuf, ExtOut& eo, int& score_out, int zstride = 64 * C) {
     const int lane = lane_id();
@@ -240,6 +243,7 @@ __device__ __forceinline__ void wave_task_run(const DevTask T, const uint8_t* __
             if (MODE == MODE_GLOBAL) {
                 dd |= (e2 > t) ? 4u : 0u;
                 dd |= (f2 > t) ? 32u : 0u;
+                if (ZEQ) dd |= (qc[c] == 8u * (uint32_t)tch) ? 64u : 0u;
                 zpack |= (act[c] ? dd : 0u) << (8 * c);
             }
             Eo[c] = (STATIC_BAND ? !dead[c] : act[c]) ? (e2 > t ? e2 : t) : FLOOR;

@@ -35,7 +35,7 @@ constexpr int BOUND_CAP = 24;       // chains tried in one region (alnBounds)
 constexpr int ALN_CAP = 8;          // alignments reported per read
 constexpr int CHAINOUT_CAP = 96;    // seeds of all reported chains of a read
 constexpr int OPS_CAP = 160;        // extended CIGAR operations of a read's reported alignments: the least a caller provides room for
-constexpr int BAM_CAP = 96;         // BAM CIGAR operations of one ksw_global call
+constexpr int BAM_CAP = 96;         // extended operations of one short ksw_global call (longer calls: the environment's memory)
 
 enum Status { DONE = 0, NEED_CALLER = 1, NO_SEED = 2, NO_ALIGNMENT = 3 };      // NEED_CALLER: the caller maps this read itself (a capacity was exceeded, the
                                                 // re-seeding rescue is due, a DP task is outside the wave kernel's envelope)
@@ -79,7 +79,7 @@ struct Work {                       // one read's state (LDS on the device)
     CigOp* ops;                                     // the read's extended CIGAR operations (caller's memory: written, never read back)
     int32_t opsCap;
     uint32_t bam[BAM_CAP];
-    const uint32_t* bamp;      // the BAM operations of the last global_cigar call: `bam`, or memory of the environment's (long pieces)
+    const uint32_t* bamp;      // the operations of the last global_cigar call: `bam`, or memory of the environment's (long pieces)
     uint16_t aorder[ALN_CAP];
     int32_t nAln, nChainOut, nOps, fail;
 };
@@ -398,43 +398,24 @@ MC_FN bool push_op(Work& W, int32_t len, char code) {
     return true;
 }
 
-// one ksw_global call of constructCIGAR (src/mapper.cpp:200,239,256) and recoverCIGAR4 (:80-117) on its result: the BAM
-// operations expanded to '=' / 'X' runs by comparing read and text; adds mismatches + gap bases to `edit`
+// one ksw_global call of constructCIGAR (src/mapper.cpp:200,239,256) and recoverCIGAR4 (:80-117) on its result.  The
+// environment returns the call's alignment as EXTENDED operations already -- len << 4 | code, code 0 '=', 1 'I', 2 'D', 3 'X',
+// adjacent operations of one kind merged, in order: the BAM operations with every M run split into maximal runs of equal /
+// unequal residues (nt4 codes are compared: n equals n) -- env.xop(W, first + k), k < n.  The device knows a cell's equality
+// while it fills the matrix and its walk writes these runs directly; the CPU build expands the oracle's BAM operations.
+// Adds mismatches + gap bases to `edit`.
+constexpr uint32_t XOP_EQ = 0, XOP_INS = 1, XOP_DEL = 2, XOP_X = 3;
 template <class Env>
 MC_FN bool dp_piece(Env& env, Work& W, bool fw, int qFrom, int qLen, int64_t tFrom, int tLen, int band, int& edit) {
     int first = 0;
     const int n = env.global_cigar(W, fw, qFrom, qLen, tFrom, tLen, band, first);
     if (n < 0) return false;
-    int x = 0, y = 0;
     for (int k = 0; k < n; ++k) {
-        const uint32_t c = W.bamp[first + k];
-        const int op = (int)(c & 0xf), len = (int)(c >> 4);
-        if (op == 0) {
-            // maximal runs of equal / unequal residues, in order (nt4 codes are compared: n equals n)
-            int run = 0;
-            bool runEq = true;
-            for (int at = 0; at < len; at += 64) {
-                const int m = len - at < 64 ? len - at : 64;
-                uint64_t eq = env.equal_mask(fw, qFrom + x + at, tFrom + y + at, m);
-                int i = 0;
-                while (i < m) {
-                    const bool e = (eq >> i) & 1;
-                    // length of the stretch of bits equal to e from i on (inside this chunk)
-                    const uint64_t diff = (e ? ~eq : eq) >> i;
-                    int st = diff ? __builtin_ctzll(diff) : 64;
-                    if (st > m - i) st = m - i;
-                    if (run > 0 && e != runEq) { if (!push_op(W, run, runEq ? '=' : 'X')) return false; run = 0; }
-                    if (!e) edit += st;
-                    runEq = e; run += st; i += st;
-                }
-            }
-            if (run > 0 && !push_op(W, run, runEq ? '=' : 'X')) return false;
-            x += len; y += len;
-        } else {
-            if (!push_op(W, len, "MIDSH"[op])) return false;
-            if (op == 1) { x += len; edit += len; }
-            else if (op == 2) { y += len; edit += len; }
-        }
+        const uint32_t c = env.xop(W, first + k);
+        const uint32_t code = c & 0xf;
+        const int len = (int)(c >> 4);
+        if (!push_op(W, len, "=IDX"[code])) return false;
+        if (code != XOP_EQ) edit += len;
     }
     return true;
 }

@@ -34,6 +34,16 @@ __device__ __forceinline__ uint8_t nt4_of(uint8_t c) {
     return l == 'a' ? 0 : l == 'c' ? 1 : l == 'g' ? 2 : l == 't' ? 3 : 4;
 }
 
+// -DALFA_MAP_PROFILE (tools/probes/map_profile.sh; never in the product build): cycles per phase, summed over all reads
+#ifdef ALFA_MAP_PROFILE
+__device__ unsigned long long g_map_prof[8];      // 0 stage, 1 ksw_nw, 2 ksw_extend, 3 ksw_global fill, 4 walk, 5 whole read, 6 reads, 7 CIGAR phase
+#define PROF_T0 const long long prof_t0 = clock64()
+#define PROF_ADD(k) prof[k] += clock64() - prof_t0
+#else
+#define PROF_T0
+#define PROF_ADD(k)
+#endif
+
 constexpr int SEQ_OFF = 16;        // wave_task's 8-byte windows may start a few bytes in front of a sequence
 constexpr int ZTILE = 4096;        // direction bytes of a ksw_global call that fit here stay in LDS, rows packed to the band's width
 
@@ -48,6 +58,12 @@ struct DevEnv {
     const alfa_region* regF; const alfa_region* regR;
     const alfa_match* memF; const alfa_match* memR;
     int nF, nR;
+#ifdef ALFA_MAP_PROFILE
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    bool xlds = true;            // xop(): where the last call's operations lie, and the window of 64 of them held in the lanes
+    int xbase = -64, xcap = 0;
+    uint32_t xwin = 0;
 
     __device__ int lane() const { return ln; }
     __device__ int lanes() const { return 64; }
@@ -79,6 +95,7 @@ struct DevEnv {
         const uint8_t* P = fw ? Pf : Pr;
         uint8_t* q = scr + SEQ_OFF;
         uint8_t* t = scr + SEQ_OFF + A.qcap + SEQ_OFF;
+        PROF_T0;
         __syncthreads();
         if (left) {          // both strings reversed: position j is j + 1 residues to the left of the anchor
             for (int j = ln; j < qLen; j += 64) q[j] = nt4_of(P[qFrom - j]);
@@ -89,6 +106,7 @@ struct DevEnv {
         }
         __threadfence_block();
         __syncthreads();
+        PROF_ADD(0);
         return true;
     }
     __device__ DevTask task(int qLen, int tLen, int w, int h0) const {
@@ -106,8 +124,10 @@ struct DevEnv {
         const DevTask T = task(qLen, tLen, w, 0);
         ExtOut eo;
         int s = 0;
+        PROF_T0;
         if (2 * w + 1 <= 128) wave_task_run<MODE_NW, 2>(T, scr, prm, nullptr, eo, s);
         else wave_task_run<MODE_NW, 4>(T, scr, prm, nullptr, eo, s);
+        PROF_ADD(1);
         score = s;
         return true;
     }
@@ -129,9 +149,11 @@ struct DevEnv {
         const DevTask T = task(qLen, rows, w, h0);
         ExtOut eo;
         int s = 0;
+        PROF_T0;
         if (2 * w + 1 <= 64) wave_task_run<MODE_EXTEND, 1, true>(T, scr, prm, nullptr, eo, s);
         else if (2 * w + 1 <= 128) wave_task_run<MODE_EXTEND, 2, true>(T, scr, prm, nullptr, eo, s);
         else wave_task_run<MODE_EXTEND, 4, true>(T, scr, prm, nullptr, eo, s);
+        PROF_ADD(2);
         r.score = eo.score; r.qle = eo.qle; r.tle = eo.tle; r.gtle = eo.gtle; r.gscore = eo.gscore; r.max_off = eo.max_off;
         return true;
     }
@@ -159,13 +181,20 @@ struct DevEnv {
         const DevTask T = task(qLen, tLen, w, 0);
         ExtOut eo;
         int s = 0;
-        if (in_lds) wave_task_run<MODE_GLOBAL, 2, false, true>(T, scr, prm, z, eo, s, wpad);
-        else if (!C4) wave_task_run<MODE_GLOBAL, 2>(T, scr, prm, z, eo, s);
-        else wave_task_run<MODE_GLOBAL, 4>(T, scr, prm, z, eo, s);
-        __threadfence_block();
-        __syncthreads();
-        uint32_t* bam = in_lds ? W.bam : (uint32_t*)(zg + A.zstride);
-        const int cap = in_lds ? mapcore::BAM_CAP : A.bam_cap;
+        {
+            PROF_T0;
+            if (in_lds) wave_task_run<MODE_GLOBAL, 2, false, true, true>(T, scr, prm, z, eo, s, wpad);
+            else if (!C4) wave_task_run<MODE_GLOBAL, 2, false, false, true>(T, scr, prm, z, eo, s);
+            else wave_task_run<MODE_GLOBAL, 4, false, false, true>(T, scr, prm, z, eo, s);
+            __threadfence_block();
+            __syncthreads();
+            PROF_ADD(3);
+        }
+        PROF_T0;
+        // the walk's operations: at most one per step, qLen + tLen steps -- LDS when that is sure to fit, else the slot
+        const bool ops_lds = qLen + tLen <= mapcore::BAM_CAP;
+        uint32_t* bam = ops_lds ? W.bam : (uint32_t*)(zg + A.zstride);
+        const int cap = ops_lds ? mapcore::BAM_CAP : A.bam_cap;
         int pos = cap, n = 0;
         uint32_t cur_op = 0xffffffffu, cur_len = 0;
         bool over = false;
@@ -176,39 +205,69 @@ struct DevEnv {
         };
         int i = tLen - 1, k = (i + w + 1 < qLen ? i + w + 1 : qLen) - 1;
         int which = 0;
-        if (in_lds) {
-            while (i >= 0 && k >= 0) {
-                const uint32_t zv = z[i * rowb + (k - i + w)];
-                which = (zv >> (which << 1)) & 3;
-                if (which == 0) { push(0, 1); --i; --k; }
-                else if (which == 1) { push(2, 1); --i; }
-                else { push(1, 1); --k; }
+        // The walk of ksw.c:524-538 is a chain of dependent one-byte reads, a few hundred cycles per step for a lone wavefront.
+        // Most steps are diagonal, though, and a diagonal run needs no chain: in state 0 the lanes read the cells (i - t, k - t),
+        // t = lane, at once (same column of the band, consecutive rows), a ballot gives the length of the run of cells whose
+        // H field says "diagonal", and their equality bits become '=' / 'X' runs by bit scans.  Gap steps stay serial.
+        const int TR = in_lds ? tLen : ZTILE / rowb;         // rows in LDS at a time: all of them, or a tile of 32 / 16
+        const uint8_t* zt = in_lds ? z : ztile;
+        int lo = in_lds ? 0 : i + 1;                         // first row of the tile in LDS (long pieces: none yet)
+        while (i >= 0 && k >= 0) {
+            if (i < lo) {                                    // every lane takes the same path: i and k are wave-uniform
+                lo = i - TR + 1 > 0 ? i - TR + 1 : 0;
+                const int bytes = (i - lo + 1) * rowb;
+                __syncthreads();
+                for (int o = ln * 16; o < bytes; o += 64 * 16) *(uint4*)(ztile + o) = *(const uint4*)(z + (int64_t)lo * rowb + o);
+                __syncthreads();
             }
-        } else {
-            const int TR = ZTILE / rowb;                     // rows of a tile: 32 (band <= 128 diagonals) or 16
-            int lo = i + 1;                                  // first row of the tile in LDS (none yet)
-            while (i >= 0 && k >= 0) {
-                if (i < lo) {                                // every lane takes the same path: i and k are wave-uniform
-                    lo = i - TR + 1 > 0 ? i - TR + 1 : 0;
-                    const int bytes = (i - lo + 1) * rowb;
-                    __syncthreads();
-                    for (int o = ln * 16; o < bytes; o += 64 * 16) *(uint4*)(ztile + o) = *(const uint4*)(z + (int64_t)lo * rowb + o);
-                    __syncthreads();
+            if (which == 0) {
+                int lim = i - lo < k ? i - lo : k;           // cells of this diagonal inside the tile (and the matrix), less one
+                lim = (lim < 63 ? lim : 63) + 1;
+                uint32_t zc = 3u;
+                if (ln < lim) zc = zt[(i - ln - lo) * rowb + (k - i + w)];
+                const uint64_t stop = __ballot(ln >= lim || (zc & 3u) != 0u);
+                const int L = stop ? __builtin_ctzll(stop) : 64;
+                if (L > 0) {
+                    const uint64_t eqm = __ballot((zc & 64u) != 0u);
+                    for (int t = 0; t < L;) {
+                        const bool e = (eqm >> t) & 1;
+                        const uint64_t diff = (e ? ~eqm : eqm) >> t;
+                        int run = diff ? __builtin_ctzll(diff) : 64;
+                        if (run > L - t) run = L - t;
+                        push(e ? mapcore::XOP_EQ : mapcore::XOP_X, (uint32_t)run);
+                        t += run;
+                    }
+                    i -= L; k -= L;
+                    continue;
                 }
-                const uint32_t zv = ztile[(i - lo) * rowb + (k - i + w)];
-                which = (zv >> (which << 1)) & 3;
-                if (which == 0) { push(0, 1); --i; --k; }
-                else if (which == 1) { push(2, 1); --i; }
-                else { push(1, 1); --k; }
             }
+            const uint32_t zv = zt[(i - lo) * rowb + (k - i + w)];
+            which = (zv >> (which << 1)) & 3;
+            if (which == 0) { push((zv & 64u) ? mapcore::XOP_EQ : mapcore::XOP_X, 1); --i; --k; }
+            else if (which == 1) { push(mapcore::XOP_DEL, 1); --i; }
+            else { push(mapcore::XOP_INS, 1); --k; }
         }
-        if (i >= 0) push(2, (uint32_t)(i + 1));
-        if (k >= 0) push(1, (uint32_t)(k + 1));
+        if (i >= 0) push(mapcore::XOP_DEL, (uint32_t)(i + 1));
+        if (k >= 0) push(mapcore::XOP_INS, (uint32_t)(k + 1));
         if (cur_op != 0xffffffffu) { if (pos > 0) bam[--pos] = cur_len << 4 | cur_op; else over = true; ++n; }
+        PROF_ADD(4);
         if (over) return -1;
         first = pos;
         W.bamp = bam;
+        xlds = ops_lds;
+        xbase = -64;
+        xcap = cap;
         return n;
+    }
+    // operation i of the last global_cigar call.  Short calls: LDS.  Long calls: the workgroup's slot in HBM, where one load per
+    // operation would be a chain of ~1 us round trips: the lanes fetch 64 operations at a time and hand them round
+    __device__ uint32_t xop(const Work& W, int i) {
+        if (xlds) return W.bam[i];
+        if ((unsigned)(i - xbase) >= 64u) {
+            xbase = i;
+            xwin = i + ln < xcap ? W.bamp[i + ln] : 0u;
+        }
+        return (uint32_t)__builtin_amdgcn_readlane((int)xwin, __builtin_amdgcn_readfirstlane(i - xbase));
     }
     // bit i: nt4(P[qpos + i]) == nt4(S[tpos + i]), i < n <= 64
     __device__ uint64_t equal_mask(bool fw, int qpos, int64_t tpos, int n) const {
@@ -252,7 +311,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 W.opsCap = A.ops_cap;
                 W.bamp = W.bam;
                 __syncthreads();
+#ifdef ALFA_MAP_PROFILE
+                const long long rt0 = clock64();
+#endif
                 status = mapcore::map_read(env, W, A.opt, A.rp[r], nreg);
+#ifdef ALFA_MAP_PROFILE
+                if (ln == 0) {
+                    env.prof[5] = clock64() - rt0; env.prof[6] = 1;
+                    for (int k = 0; k < 7; ++k) atomicAdd(&g_map_prof[k], (unsigned long long)env.prof[k]);
+                }
+#endif
                 why = W.fail;
                 if (status == mapcore::DONE) {
                     naln = W.nAln; nseed = W.nChainOut; nops = W.nOps;
@@ -301,6 +369,14 @@ int map_resident_workgroups() {
     }();
     return v;
 }
+
+#ifdef ALFA_MAP_PROFILE
+extern "C" int alfa_map_profile(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_map_prof), sizeof(g_map_prof)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_map_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 void launch_map(hipStream_t st, const MapKernelArgs& a) {
     if (a.n <= 0 || a.slots <= 0) return;

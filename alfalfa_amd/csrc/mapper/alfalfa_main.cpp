@@ -31,6 +31,12 @@ int main(int argc, char** argv) {
     mallopt(M_MMAP_THRESHOLD, 1 << 30);
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
     mallopt(M_TOP_PAD, 64 << 20);
+    if (const char* m = getenv("ALFA_SYNC")) {            // how a host thread waits for the GPU: block (sleep), yield, spin; default: HIP's choice
+        const unsigned f = m[0] == 'b' ? hipDeviceScheduleBlockingSync : m[0] == 'y' ? hipDeviceScheduleYield : m[0] == 's' ? hipDeviceScheduleSpin : hipDeviceScheduleAuto;
+        const int nd = alfa_device_count();
+        for (int d = 0; d < nd; ++d) { (void)hipSetDevice(d); (void)hipSetDeviceFlags(f); }
+        if (nd > 0) (void)hipSetDevice(0);
+    }
     alfa::HotBinding b;
     b.make_ops = [](int device, const alfa_host_index* hidx, alfa::HotOps* ops) {
         device = physical(device);

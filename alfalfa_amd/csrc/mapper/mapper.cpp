@@ -735,8 +735,9 @@ struct CoreEnv {
         r.score = e.score; r.qle = e.qle; r.tle = e.tle; r.gtle = e.gtle; r.gscore = e.gscore; r.max_off = e.max_off;
         return true;
     }
-    // ksw_global through the scheduler; the BAM operations stay in this object, W.bamp points at them
-    std::vector<uint32_t> cg;
+    // ksw_global through the scheduler; its BAM operations expanded to extended operations (recoverCIGAR4 src/mapper.cpp:80-117:
+    // every M run split into maximal runs of equal / unequal nt4 codes), kept in this object
+    std::vector<uint32_t> cg, xs;
     int global_cigar(mapcore::Work& W, bool fw, int qFrom, int qLen, int64_t tFrom, int tLen, int band, int& first) {
         const uint8_t* rp = fw ? read.readP.data() : read.rcReadP.data();
         const char* S = idx.S();
@@ -746,10 +747,26 @@ struct CoreEnv {
         cg.clear();
         hot.submit_global(GlobalReq{alfa_dp_task{rp + qFrom, t.data(), qLen, tLen, band, 0}, &score, &cg});
         hot.wait();
+        xs.clear();
+        auto put = [&](uint32_t code, uint32_t len) {
+            if (!xs.empty() && (xs.back() & 0xf) == code) xs.back() += len << 4;
+            else xs.push_back(len << 4 | code);
+        };
+        int x = 0, y = 0;
+        for (const uint32_t c : cg) {
+            const int op = (int)(c & 0xf), len = (int)(c >> 4);
+            if (op == 0) {
+                for (int k = 0; k < len; ++k) put(rp[qFrom + x + k] == t[(size_t)(y + k)] ? mapcore::XOP_EQ : mapcore::XOP_X, 1);
+                x += len; y += len;
+            } else if (op == 1) { put(mapcore::XOP_INS, (uint32_t)len); x += len; }
+            else if (op == 2) { put(mapcore::XOP_DEL, (uint32_t)len); y += len; }
+            else return -1;
+        }
         first = 0;
-        W.bamp = cg.data();
-        return (int)cg.size();
+        W.bamp = xs.data();
+        return (int)xs.size();
     }
+    uint32_t xop(const mapcore::Work& W, int i) const { return W.bamp[i]; }
     uint64_t equal_mask(bool fw, int qpos, int64_t tpos, int n) const {
         const uint8_t* rp = fw ? read.readP.data() : read.rcReadP.data();
         const char* S = idx.S();
