@@ -24,6 +24,14 @@
 #ifndef MC_FN
 #define MC_FN inline
 #endif
+// phase timers of the profiling build of the kernel (map_kernels.hip under -DALFA_MAP_PROFILE); nothing anywhere else
+#if defined(ALFA_MAP_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define MC_T0(v) const long long v = clock64()
+#define MC_ADD(env, k, v) (env).prof[k] += clock64() - v
+#else
+#define MC_T0(v)
+#define MC_ADD(env, k, v)
+#endif
 
 namespace alfa {
 namespace mapcore {
@@ -224,6 +232,7 @@ template <class Env>
 MC_FN int try_region(Env& env, Work& W, const Options& O, const ReadParams& R, int n, bool fw, int minScore, int minCoverage,
                      int64_t chrStart, int64_t chrEnd) {
     int best = minScore - 10 < -1 ? minScore - 10 : -1;
+    MC_T0(t_rank);
     // anchors: by (length, index) ascending, tried from the back (:885-893)
     for (int i = env.lane(); i < n; i += env.lanes()) {
         const int32_t l = W.ml[i];
@@ -233,6 +242,7 @@ MC_FN int try_region(Env& env, Work& W, const Options& O, const ReadParams& R, i
         W.used[i] = 0;
     }
     env.sync();
+    MC_ADD(env, 11, t_rank);
     int nBounds = 0, nAcc = 0;
     const int plen = R.plen, editDist = R.editDist;
     for (int oi = n - 1; oi >= 0; --oi) {
@@ -259,7 +269,9 @@ MC_FN int try_region(Env& env, Work& W, const Options& O, const ReadParams& R, i
         }
         if (!go) continue;
         int score, nFwd, nBack;
+        MC_T0(t_gc);
         const int minEdit = grow_chain(W, n, a, O.errorPercent, plen, score, nFwd, nBack);      // the score starts as the chain's coverage
+        MC_ADD(env, 12, t_gc);
         const int chainLen = nBack + 1 + nFwd;
         if (!(minEdit <= editDist && (chainLen > 1 || aL >= minCoverage))) continue;
         const int band = O.fixedBandSize < editDist - minEdit + 1 ? O.fixedBandSize : editDist - minEdit + 1;
@@ -363,14 +375,20 @@ MC_FN void run_regions(Env& env, Work& W, const Options& O, const ReadParams& R,
     for (int li = 0; li < nRegions && W.nAln < maxAln && !W.fail; ++li) {
         int n, score;
         bool fw;
+        MC_T0(t_lr);
         if (!env.load_region(W, W.rorder[li], n, fw, score)) { W.fail = 10; return; }
+        MC_ADD(env, 8, t_lr);
         const int s = fw ? 1 : 0;
+        MC_T0(t_cn);
         const bool unique = covers_new_bases(W, s, n);
+        MC_ADD(env, 9, t_cn);
         if (W.fail) return;
         if ((trial[s] < O.maxTrial || unique) && (n > 1 || score >= minCoverage)) {
             int64_t cs, ce;
             env.chrom_bounds(W.mref[0], cs, ce);
+            MC_T0(t_tr);
             const int ret = try_region(env, W, O, R, n, fw, minScore, minCoverage, cs, ce);
+            MC_ADD(env, 10, t_tr);
             if (W.fail) return;
             trial[s]++;
             if (ret >= 0 && (!O.maxTrialBest || bestSoFar < ret)) trial[s] = 0;
@@ -509,7 +527,9 @@ MC_FN int map_read(Env& env, Work& W, const Options& O, const ReadParams& R, int
         if (W.fail) return NEED_CALLER;
         if (W.nAln == 0 && !O.rescueOnly) { W.fail = 11; return NO_ALIGNMENT; }      // RESCUE2 (:1290-1300) is a call of its own
     }
+    MC_T0(t_bc);
     if (O.cigarCount > 0) build_cigars(env, W, O, R);
+    MC_ADD(env, 14, t_bc);
     return DONE;
 }
 

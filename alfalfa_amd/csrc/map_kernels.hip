@@ -36,7 +36,7 @@ __device__ __forceinline__ uint8_t nt4_of(uint8_t c) {
 
 // -DALFA_MAP_PROFILE (tools/probes/map_profile.sh; never in the product build): cycles per phase, summed over all reads
 #ifdef ALFA_MAP_PROFILE
-__device__ unsigned long long g_map_prof[8];      // 0 stage, 1 ksw_nw, 2 ksw_extend, 3 ksw_global fill, 4 walk, 5 whole read, 6 reads, 7 CIGAR phase
+__device__ unsigned long long g_map_prof[16];     // 0 stage, 1 ksw_nw, 2 ksw_extend, 3 ksw_global fill, 4 walk, 5 whole read, 6 reads, 8.. map_core.h's timers
 #define PROF_T0 const long long prof_t0 = clock64()
 #define PROF_ADD(k) prof[k] += clock64() - prof_t0
 #else
@@ -59,7 +59,7 @@ struct DevEnv {
     const alfa_match* memF; const alfa_match* memR;
     int nF, nR;
 #ifdef ALFA_MAP_PROFILE
-    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     bool xlds = true;            // xop(): where the last call's operations lie, and the window of 64 of them held in the lanes
     int xbase = -64, xcap = 0;
@@ -125,7 +125,8 @@ struct DevEnv {
         ExtOut eo;
         int s = 0;
         PROF_T0;
-        if (2 * w + 1 <= 128) wave_task_run<MODE_NW, 2>(T, scr, prm, nullptr, eo, s);
+        if (2 * w + 1 <= 64) wave_task_run<MODE_NW, 1>(T, scr, prm, nullptr, eo, s);          // (a row costs by cells per lane, not by band width)
+        else if (2 * w + 1 <= 128) wave_task_run<MODE_NW, 2>(T, scr, prm, nullptr, eo, s);
         else wave_task_run<MODE_NW, 4>(T, scr, prm, nullptr, eo, s);
         PROF_ADD(1);
         score = s;
@@ -166,6 +167,7 @@ struct DevEnv {
         if (w > lim) w = lim;
         if (w < 0 || 2 * w + 1 > 256 || tLen > qLen + w) return -1;      // (tlen > qlen + w: the reference indexes outside its matrix)
         const int C4 = 2 * w + 1 > 128;
+        const bool C1 = 2 * w + 1 <= 64;                     // one cell per lane: the cheapest row
         // short pieces (the common case on short reads: a gap or an overhang of a few dozen residues) keep their direction
         // bytes in LDS, rows packed to the band's width -- the walk is a chain of dependent reads, 60 of them through HBM were
         // half of the kernel's time.  Longer ones (long reads: pieces of hundreds to thousands of rows) go to the workgroup's
@@ -173,7 +175,7 @@ struct DevEnv {
         // operations go to the slot as well.
         const int wpad = (2 * w + 1 + 4) & ~3;               // > 2w + 1, a multiple of 4
         const bool in_lds = !C4 && tLen * wpad <= ZTILE;
-        const int rowb = in_lds ? wpad : (C4 ? 256 : 128);
+        const int rowb = in_lds ? wpad : (C4 ? 256 : C1 ? 64 : 128);
         if (!in_lds && (int64_t)tLen * rowb > A.zstride) return -1;
         if (!stage(fw, false, qFrom, qLen, tFrom, tLen)) return -1;
         uint8_t* zg = A.zscratch + (int64_t)slot * A.zslot;
@@ -183,7 +185,9 @@ struct DevEnv {
         int s = 0;
         {
             PROF_T0;
-            if (in_lds) wave_task_run<MODE_GLOBAL, 2, false, true, true>(T, scr, prm, z, eo, s, wpad);
+            if (in_lds && C1) wave_task_run<MODE_GLOBAL, 1, false, true, true>(T, scr, prm, z, eo, s, wpad);
+            else if (in_lds) wave_task_run<MODE_GLOBAL, 2, false, true, true>(T, scr, prm, z, eo, s, wpad);
+            else if (C1) wave_task_run<MODE_GLOBAL, 1, false, false, true>(T, scr, prm, z, eo, s);
             else if (!C4) wave_task_run<MODE_GLOBAL, 2, false, false, true>(T, scr, prm, z, eo, s);
             else wave_task_run<MODE_GLOBAL, 4, false, false, true>(T, scr, prm, z, eo, s);
             __threadfence_block();
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #ifdef ALFA_MAP_PROFILE
                 if (ln == 0) {
                     env.prof[5] = clock64() - rt0; env.prof[6] = 1;
-                    for (int k = 0; k < 7; ++k) atomicAdd(&g_map_prof[k], (unsigned long long)env.prof[k]);
+                    for (int k = 0; k < 16; ++k) atomicAdd(&g_map_prof[k], (unsigned long long)env.prof[k]);
                 }
 #endif
                 why = W.fail;
@@ -371,9 +375,9 @@ int map_resident_workgroups() {
 }
 
 #ifdef ALFA_MAP_PROFILE
-extern "C" int alfa_map_profile(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_map_prof), sizeof(g_map_prof)) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_map_prof), z, sizeof(z)) != hipSuccess) return 1; }
+extern "C" int alfa_map_profile(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_map_prof), sizeof(g_map_prof)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_map_prof), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
 #endif

@@ -29,7 +29,7 @@ ffi.index_build_on_device(-1)
 didx = ffi.DeviceIndex(hidx, 0)
 P = ffi.default_params()
 reads = ffi.make_map_reads(fw, rc, 12, opt)
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 for rep in range(2):
     ffi.lib().alfa_map_profile(out, 1)
     res = ffi.map_reads_batch(didx, opt, P, reads)
@@ -40,3 +40,5 @@ for rep in range(2):
     print("%s rep %d: %d reads, map_kernel %.2f ms; cycles per read %.0f; share of a read's cycles: %s; rest (trial loop, operations, chains) %.1f %%" %
           (cfg, rep, v[6], ffi.last_timing().kernel_ms, tot / max(v[6], 1),
            ", ".join("%s %.1f %%" % (names[k], 100.0 * v[k] / tot) for k in range(5)), 100.0 * (tot - sum(v[:5])) / tot), flush=True)
+    print("   inclusive: load_region %.1f %%, covers_new_bases %.1f %%, try_region %.1f %% (anchor ranks %.1f %%, grow_chain %.1f %%), build_cigars %.1f %%" %
+          tuple(100.0 * v[k] / tot for k in (8, 9, 10, 11, 12, 14)), flush=True)
