@@ -426,6 +426,7 @@ constexpr uint32_t XOP_EQ = 0, XOP_INS = 1, XOP_DEL = 2, XOP_X = 3;
 template <class Env>
 MC_FN bool dp_piece(Env& env, Work& W, bool fw, int qFrom, int qLen, int64_t tFrom, int tLen, int band, int& edit) {
     int first = 0;
+    MC_T0(t_dp);
     const int n = env.global_cigar(W, fw, qFrom, qLen, tFrom, tLen, band, first);
     if (n < 0) return false;
     for (int k = 0; k < n; ++k) {
@@ -435,6 +436,7 @@ MC_FN bool dp_piece(Env& env, Work& W, bool fw, int qFrom, int qLen, int64_t tFr
         if (!push_op(W, len, "=IDX"[code])) return false;
         if (code != XOP_EQ) edit += len;
     }
+    MC_ADD(env, 13, t_dp);
     return true;
 }
 

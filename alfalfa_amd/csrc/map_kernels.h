@@ -55,6 +55,8 @@ struct MapKernelArgs {
 // workgroups one launch can keep resident (what `slots` is worth at most)
 int map_resident_workgroups();
 void launch_map(hipStream_t st, const MapKernelArgs& a);
+// exclusive prefix sums of three int32 arrays of n1 entries in one launch (for the arrays of a call: up to ~10^6 entries; beyond, a library scan)
+void launch_map_offsets(hipStream_t st, int n1, const int32_t* a, const int32_t* b, const int32_t* c, int32_t* oa, int32_t* ob, int32_t* oc);
 // dense copies of the slotted results: read r's alignments to out_alns[aln_off[r] ..], its chain seeds to out_seeds[seed_off[r] ..],
 // its CIGAR operations to out_ops[op_off[r] ..]
 void launch_map_compact(hipStream_t st, int n, const int32_t* naln, const int32_t* nseed, const int32_t* nops, const int32_t* aln_off,

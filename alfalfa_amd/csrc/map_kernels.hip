@@ -135,6 +135,9 @@ struct DevEnv {
     // ksw_extend(qLen, query, tLen, target, 5, mat, gapo, gape, w, 100, h0, ...)   src/ksw.c:362, call sites src/mapper.cpp:802,845
     // left: query[j] = P[qAnchor - 1 - j], target[j] = S[tAnchor - 1 - j]; right: query[j] = P[qAnchor + 1 + j], target[j] = S[tAnchor + 1 + j]
     __device__ bool extend(bool fw, bool left, int qAnchor, int qLen, int64_t tAnchor, int tLen, int w, int h0, ExtRes& r) {
+#ifdef ALFA_MAP_PROFILE
+        struct Incl { long long& acc; long long t0; __device__ ~Incl() { acc += clock64() - t0; } } incl{prof[15], clock64()};
+#endif
         // effective band and rows exactly as the batch entry point derives them (ksw_kernels.hip: effective_w, rows_eff)
         const int gapo = prm->gapo, gape = prm->gape, maxs = prm->maxs;
         int max_gap = gape > 0 ? (int)((double)(qLen * maxs - gapo) / gape + 1.) : 0x3fffffff;
@@ -162,6 +165,9 @@ struct DevEnv {
     // fill writes one direction byte per cell to this read's slot of A.zscratch, then the walk of ksw.c:524-538 (every lane
     // the same steps) leaves the BAM operations in forward order at W.bam[first .. first + n).  -1: not done here.
     __device__ int global_cigar(Work& W, bool fw, int qFrom, int qLen, int64_t tFrom, int tLen, int w, int& first) {
+#ifdef ALFA_MAP_PROFILE
+        struct Incl { long long& acc; long long t0; __device__ ~Incl() { acc += clock64() - t0; } } incl{prof[7], clock64()};
+#endif
         if (qLen < 1 || tLen < 1) return -1;                 // degenerate calls (the reference's loops do not run): the caller's path
         const int lim = qLen > tLen ? qLen : tLen;
         if (w > lim) w = lim;
@@ -359,7 +365,44 @@ __global__ void map_compact_kernel(int n, const int32_t* __restrict__ naln, cons
     for (int k = threadIdx.x; k < no; k += blockDim.x) out_ops[op_off[r] + k] = ops[(int64_t)r * ops_cap + k];
 }
 
+// exclusive prefix sums of the three per-read count arrays (n1 = n + 1 entries each), one workgroup per array: a call's
+// arrays are a few ten thousand entries, for which a library scan's two launches each cost more than the scan
+constexpr int OFFS_ITEMS = 4;
+__global__ __launch_bounds__(1024) void map_offsets_kernel(int n1, const int32_t* __restrict__ a, const int32_t* __restrict__ b, const int32_t* __restrict__ c,
+                                                          int32_t* __restrict__ oa, int32_t* __restrict__ ob, int32_t* __restrict__ oc) {
+    const int32_t* __restrict__ in = blockIdx.x == 0 ? a : blockIdx.x == 1 ? b : c;
+    int32_t* __restrict__ out = blockIdx.x == 0 ? oa : blockIdx.x == 1 ? ob : oc;
+    __shared__ int32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int32_t carry = 0;
+    for (int start = 0; start < n1; start += 1024 * OFFS_ITEMS) {
+        const int at = start + tid * OFFS_ITEMS;
+        int32_t v[OFFS_ITEMS];
+        int32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < OFFS_ITEMS; ++k) { v[k] = at + k < n1 ? in[at + k] : 0; mine += v[k]; }
+        int32_t inc = mine;                                  // inclusive scan over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int32_t before = carry, total = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int32_t w = wsum[k]; if (k < wv) before += w; total += w; }
+        int32_t run = before + inc - mine;
+#pragma unroll
+        for (int k = 0; k < OFFS_ITEMS; ++k) { if (at + k < n1) out[at + k] = run; run += v[k]; }
+        carry += total;
+        __syncthreads();
+    }
+}
+
 }  // namespace
+
+void launch_map_offsets(hipStream_t st, int n1, const int32_t* a, const int32_t* b, const int32_t* c, int32_t* oa, int32_t* ob, int32_t* oc) {
+    if (n1 <= 0) return;
+    hipLaunchKernelGGL(map_offsets_kernel, dim3(3), dim3(1024), 0, st, n1, a, b, c, oa, ob, oc);
+}
 
 // 3 wavefronts per SIMD (the kernel's registers) and the LDS of a CU both allow 12 one-wave workgroups per CU
 int map_resident_workgroups() {

@@ -2442,12 +2442,16 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     alfa::launch_map(st, A);
     ALFA_HIP(hipGetLastError());
     ALFA_HIP(hipEventRecord(pl->mev1, st));
-    size_t tb = tmp_bytes;
-    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(dA + o_tmp, tb, d_naln, d_aoff, n + 1, st));
-    tb = tmp_bytes;
-    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(dA + o_tmp, tb, d_nseed, d_soff, n + 1, st));
-    tb = tmp_bytes;
-    ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(dA + o_tmp, tb, d_nops, d_ooff, n + 1, st));
+    if (n + 1 <= (1 << 20) && !getenv("ALFA_MAP_SCAN_LIB")) alfa::launch_map_offsets(      // (the variable: tests compare the two paths)
+        st, n + 1, d_naln, d_nseed, d_nops, d_aoff, d_soff, d_ooff);
+    else {
+        size_t tb = tmp_bytes;
+        ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(dA + o_tmp, tb, d_naln, d_aoff, n + 1, st));
+        tb = tmp_bytes;
+        ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(dA + o_tmp, tb, d_nseed, d_soff, n + 1, st));
+        tb = tmp_bytes;
+        ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(dA + o_tmp, tb, d_nops, d_ooff, n + 1, st));
+    }
     alfa::launch_map_compact(st, n, d_naln, d_nseed, d_nops, d_aoff, d_soff, d_ooff, A.alns, A.seeds, A.ops, ops_cap, (alfa::mapcore::AlnOut*)(dA + o_aln2),
                              (alfa_match*)(dA + o_seed2), (alfa::mapcore::CigOp*)(dA + o_ops2));
     ALFA_HIP(hipGetLastError());

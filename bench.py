@@ -861,6 +861,9 @@ def main():
             "kernel": ("sorted_keys_kernel + hipCUB radix sort + sorted_eval_kernel (queries in 10-mer order: the index is beyond the caches)"
                        if timed[0][0].sorted else "smam_count_kernel"),
             "bound": "hbm",
+            "share_of_a_run": "this is the dominant kernel of the REPLAY (the batch entry points); in the end-to-end run that `value` measures the "
+                              "seed kernels are 8 % (C3) / 4 % (C4) of the GPU time and map_kernel 47-57 % / 89 % (profiles/r03_cli_c*_kernel_trace_stats.csv): "
+                              "see roofline_map",
             "limiter": "latency / instruction issue, not bandwidth: a gather kernel (FETCH_SIZE = algorithmic bytes, L2 hit rate "
                        "and wave wait fraction in profiles/*_seed_limiter.json)",
             "limiter_counters": occupancy,

@@ -115,6 +115,13 @@ def test_map_batch_properties_and_determinism(c3):
     res2 = ffi.map_reads_batch(didx, opt, P, reads)
     for x, y in zip(res, res2):
         assert np.array_equal(x, y)
+    os.environ["ALFA_MAP_SCAN_LIB"] = "1"           # offsets by the library scan (the path of calls beyond 2^20 reads) instead of map_offsets_kernel
+    try:
+        res3 = ffi.map_reads_batch(didx, opt, P, reads)
+    finally:
+        del os.environ["ALFA_MAP_SCAN_LIB"]
+    for x, y in zip(res, res3):
+        assert np.array_equal(x, y)
     st, aoff, al, soff, sd, ooff, ops = res
     sub = slice(0, 4000)
     checked = _check_batch(ref, fw[sub], rc[sub], opt, ffi.map_reads_batch(didx, opt, P, ffi.make_map_reads(fw[sub], rc[sub], 12, opt)))

@@ -40,5 +40,5 @@ for rep in range(2):
     print("%s rep %d: %d reads, map_kernel %.2f ms; cycles per read %.0f; share of a read's cycles: %s; rest (trial loop, operations, chains) %.1f %%" %
           (cfg, rep, v[6], ffi.last_timing().kernel_ms, tot / max(v[6], 1),
            ", ".join("%s %.1f %%" % (names[k], 100.0 * v[k] / tot) for k in range(5)), 100.0 * (tot - sum(v[:5])) / tot), flush=True)
-    print("   inclusive: load_region %.1f %%, covers_new_bases %.1f %%, try_region %.1f %% (anchor ranks %.1f %%, grow_chain %.1f %%), build_cigars %.1f %%" %
-          tuple(100.0 * v[k] / tot for k in (8, 9, 10, 11, 12, 14)), flush=True)
+    print("   inclusive: load_region %.1f %%, covers_new_bases %.1f %%, try_region %.1f %% (anchor ranks %.1f %%, grow_chain %.1f %%, env.extend %.1f %%), build_cigars %.1f %% (dp_piece %.1f %%, env.global_cigar %.1f %%)" %
+          tuple(100.0 * v[k] / tot for k in (8, 9, 10, 11, 12, 15, 14, 13, 7)), flush=True)
