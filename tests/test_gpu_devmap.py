@@ -209,6 +209,17 @@ def test_cli_device_path_equals_host_trials_and_counts(gpu):
                 m = re.search(r"#CORE reads_done (\d+) handed_back (\d+)", p.stderr.decode())
                 assert m and int(m.group(1)) > 2000, (extra, m and m.group(0))
         assert outs[0] == outs[1], extra
+    # the same reads through the general formatter (read / alignment objects for every read) and with one device call at a time:
+    # the direct renderer and the barrier-free slices change nothing in the output
+    base = None
+    for env in ({}, {"ALFA_NO_DIRECT_RENDER": "1"}, {"ALFA_MAP_LANES": "1"}):
+        out = os.path.join(d, "devmap_env.sam")
+        p = subprocess.run([M.GPU_EXE, "align", "-i", pre, "-0", "synse.fq", "-o", out, "-t", "5", "--map-batch", "300"], cwd=d,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()[-1000:]
+        body = M.sam_body(out)
+        base = body if base is None else base
+        assert body == base, env
     # paired mode 1: each mate is a read of the device batch
     body, err = M.run_synth(M.GPU_EXE, "synpe_strict_pairs", ["-t", "4", "--stats"])
     assert M.md5(body) == M.synth_md5("synpe_strict_pairs")
