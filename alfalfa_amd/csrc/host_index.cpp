@@ -451,6 +451,32 @@ int alfa_host_index_load(const char* prefix, alfa_host_index** out) {
     return ALFA_OK;
 }
 
+// the host side's share of an index whose arrays go straight to device memory (alfa_index_load_to_device): .aux and .ref only
+int alfa_host_index_load_text(const char* prefix, alfa_host_index** out) {
+    if (!prefix || !out) return alfa::fail(ALFA_EINVAL, "null argument");
+    std::string b(prefix);
+    std::ifstream a((b + ".aux").c_str());
+    if (!a.is_open()) return alfa::fail(ALFA_EINVAL, "unable to open " + b + ".aux");
+    alfa_host_index* ix = new alfa_host_index();
+    std::string line;
+    auto next_long = [&]() { std::getline(a, line); return (int64_t)atol(line.c_str()); };
+    ix->N = next_long(); ix->K = next_long(); ix->logN = next_long(); ix->NKm1 = next_long();
+    ix->hasSufLink = next_long() == 1; ix->hasChild = next_long() == 1; ix->hasKmer = next_long() == 1;
+    int nchr = (int)next_long();
+    for (int i = 0; i < nchr; i++) ix->startpos.push_back(next_long());
+    for (int i = 0; i < nchr; i++) { std::getline(a, line); ix->descr.push_back(line); }
+    {
+        std::ifstream r((b + ".ref").c_str(), std::ios::binary);
+        std::getline(r, ix->S);
+    }
+    if ((int64_t)ix->S.size() != ix->N || ix->N <= 0 || nchr <= 0) { delete ix; return alfa::fail(ALFA_EINVAL, "index files of " + b + " are missing or truncated"); }
+    ix->S.append(16, '\0');
+    ix->refresh_view();
+    ix->view.SA = nullptr; ix->view.LCP = nullptr; ix->view.n = 0;       // (no arrays on the host: alfa_index_upload refuses this view)
+    *out = ix;
+    return ALFA_OK;
+}
+
 const alfa_index_view* alfa_host_index_view(const alfa_host_index* ix) { return ix ? &ix->view : nullptr; }
 const char* alfa_host_index_descr(const alfa_host_index* ix, int seq) {
     return (ix && seq >= 0 && seq < (int)ix->descr.size()) ? ix->descr[seq].c_str() : nullptr;

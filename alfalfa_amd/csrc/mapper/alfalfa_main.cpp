@@ -44,12 +44,7 @@ int main(int argc, char** argv) {
     static std::thread hip_start;
     if (argc > 1 && std::string(argv[1]) == "align") hip_start = std::thread([] { (void)hipFree(nullptr); });
     alfa::HotBinding b;
-    b.make_ops = [](int device, const alfa_host_index* hidx, alfa::HotOps* ops) {
-        if (hip_start.joinable()) hip_start.join();
-        device = physical(device);
-        alfa_index* dix = nullptr;
-        int rc = alfa_index_upload(alfa_host_index_view(hidx), device, &dix);
-        if (rc) return rc;
+    static auto fill_ops = [](alfa_index* dix, alfa::HotOps* ops) {
         ops->index = dix;
         ops->seed_batch = [](void* ix, int type, const alfa_seed_query* q, int nq, alfa_match** m, int64_t* off) {
             return alfa_seed_batch((alfa_index*)ix, type, q, nq, m, off);
@@ -68,6 +63,21 @@ int main(int argc, char** argv) {
         ops->ksw_align_batch = alfa_ksw_align_batch;
         ops->free_fn = alfa_free;
         ops->last_error = alfa_last_error;
+    };
+    b.make_ops = [](int device, const alfa_host_index* hidx, alfa::HotOps* ops) {
+        if (hip_start.joinable()) hip_start.join();
+        alfa_index* dix = nullptr;
+        int rc = alfa_index_upload(alfa_host_index_view(hidx), physical(device), &dix);
+        if (rc) return rc;
+        fill_ops(dix, ops);
+        return 0;
+    };
+    b.load_ops = [](const char* prefix, int device, alfa_host_index** hidx, alfa::HotOps* ops) {
+        if (hip_start.joinable()) hip_start.join();
+        alfa_index* dix = nullptr;
+        int rc = alfa_index_load_to_device(prefix, physical(device), hidx, &dix);
+        if (rc) return rc;
+        fill_ops(dix, ops);
         return 0;
     };
     b.release_ops = [](alfa::HotOps* ops) { alfa_index_free((alfa_index*)ops->index); };

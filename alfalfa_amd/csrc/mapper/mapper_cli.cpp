@@ -438,7 +438,24 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         alfa_host_index_free(hidx);
         return 0;
     }
-    if (o.indexLocation.empty() || alfa_host_index_load(o.indexLocation.c_str(), &hidx) != 0) {
+    const int T = std::max(1, o.threads);
+    const int G = std::max(1, o.gpus);
+    std::vector<HotOps> ops((size_t)G);
+    // A saved index goes straight from its files to the GPUs when the binding can do that (the arrays never pass through host
+    // vectors; the host keeps the text, the names and the offsets): ALFA_HOST_INDEX_LOAD=1 keeps the two-step path
+    bool ops_ready = false;
+    if (!o.indexLocation.empty() && bind.load_ops && !o.saveIndex && getenv("ALFA_HOST_INDEX_LOAD") == nullptr) {
+        ops_ready = true;
+        for (int g = 0; g < G && ops_ready; ++g)
+            if (bind.load_ops(o.indexLocation.c_str(), o.device + g, &hidx, &ops[g]) != 0) {
+                for (int k = 0; k < g; ++k) bind.release_ops(&ops[k]);
+                if (hidx) { alfa_host_index_free(hidx); hidx = nullptr; }
+                ops.assign((size_t)G, HotOps());
+                ops_ready = false;
+            }
+    }
+    if (ops_ready) {
+    } else if (o.indexLocation.empty() || alfa_host_index_load(o.indexLocation.c_str(), &hidx) != 0) {
         if (o.ref_fasta.empty()) { fprintf(stderr, "ERROR: index %s could not be loaded and no reference given\n", o.indexLocation.c_str()); return 1; }
         if (alfa_host_index_build_fasta(o.ref_fasta.c_str(), o.K, o.hasSuflink, o.hasChild, o.hasKmer, &hidx)) {
             fprintf(stderr, "ERROR: %s\n", alfa_last_error());
@@ -457,10 +474,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     memcpy(prm.mat, o.aln.mat, 25);
     prm.gapo = -o.aln.openGap; prm.gape = -o.aln.extendGap; prm.zdrop = 100;   // call sites src/mapper.cpp:787-804
 
-    const int T = std::max(1, o.threads);
-    const int G = std::max(1, o.gpus);
-    std::vector<HotOps> ops((size_t)G);
-    for (int g = 0; g < G; ++g)
+    for (int g = 0; g < G && !ops_ready; ++g)
         if (bind.make_ops(o.device + g, hidx, &ops[g])) { fprintf(stderr, "ERROR: cannot set up the hot path on device %d: %s\n", o.device + g, bind.last_error()); return 1; }
 
     const double t_device_ready = since_start();

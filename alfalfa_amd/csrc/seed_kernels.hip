@@ -39,6 +39,7 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/alfa_index.h"
 #include "device_ctx.h"
 #include "ksw_wave.h"
 #include "map_kernels.h"
@@ -1752,6 +1753,145 @@ int alfa_index_upload(const alfa_index_view* v, int device, alfa_index** out) {
             return rc;
         }
     }
+    *out = ix;
+    return ALFA_OK;
+}
+
+// ---- index files straight to device memory (second half; sparseSA::load src/sparseSA.cpp:390-476)
+namespace {
+// the 10-mer table's device companions from arrays that are already on the device (alfa_index_upload derives them on the host)
+__global__ void kmr2_kernel(const uint2* __restrict__ KMR, const uint32_t* __restrict__ SA, const uint8_t* __restrict__ S0, int64_t n, int64_t N,
+                            uint4* __restrict__ K2) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= TABLE) return;
+    const uint2 e = KMR[i];
+    const uint32_t l = e.x, r = e.y;
+    const uint32_t sa = (l < (uint64_t)n) ? SA[l] : 0u;
+    uint32_t nxt = 0;
+    if (r > l) nxt = (l + 1 < (uint64_t)n) ? SA[l + 1] : 0u;
+    else if ((int64_t)sa + KMER + 4 <= N + 16) {            // S0 = S[0]: zero bytes behind the text, as the host copy has
+        const uint8_t* p = S0 + sa + KMER;
+        nxt = (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+    }
+    K2[i] = make_uint4(l, r, sa, nxt);
+}
+
+// `bytes` of file f (from its current position) into b, through two pinned buffers: the read of one chunk overlaps the copy of the last
+int stream_file(FILE* f, alfa::DevBuf& b, size_t bytes, size_t pad, hipStream_t st, alfa::PinBuf pin[2], hipEvent_t ev[2]) {
+    int rc = b.reserve(bytes + pad + 16);
+    if (rc) return rc;
+    constexpr size_t CH = (size_t)32 << 20;
+    size_t done = 0;
+    for (int k = 0; done < bytes; ++k) {
+        const int s = k & 1;
+        const size_t m = std::min(CH, bytes - done);
+        if ((rc = pin[s].reserve(CH))) return rc;
+        if (k >= 2) ALFA_HIP(hipEventSynchronize(ev[s]));           // the copy that last used this buffer
+        if (fread(pin[s].p, 1, m, f) != m) return alfa::fail(ALFA_EINVAL, "index file truncated");
+        ALFA_HIP(hipMemcpyAsync((char*)b.p + done, pin[s].p, m, hipMemcpyHostToDevice, st));
+        ALFA_HIP(hipEventRecord(ev[s], st));
+        done += m;
+    }
+    if (pad) ALFA_HIP(hipMemsetAsync((char*)b.p + bytes, 0, pad, st));
+    ALFA_HIP(hipStreamSynchronize(st));
+    return ALFA_OK;
+}
+}  // namespace
+
+int alfa_index_load_to_device(const char* prefix, int device, alfa_host_index** host, alfa_index** out) {
+    if (!prefix || !host || !out) return alfa::fail(ALFA_EINVAL, "null argument");
+    int rc;
+    const bool own_host = *host == nullptr;
+    if (own_host && (rc = alfa_host_index_load_text(prefix, host))) return rc;
+    const alfa_index_view* v = alfa_host_index_view(*host);
+    alfa::Ctx* cx = alfa::thread_ctx(device);
+    if (!cx) { if (own_host) { alfa_host_index_free(*host); *host = nullptr; } return ALFA_ENODEV; }
+    alfa_index* ix = new alfa_index();
+    ix->device = device;
+    ix->N = v->N; ix->K = v->K; ix->logN = v->logN; ix->NKm1 = v->NKm1;
+    alfa::PinBuf pin[2];
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::vector<FILE*> open_files;
+    auto fail_out = [&](int code) {
+        for (FILE* f : open_files) fclose(f);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        pin[0].release(); pin[1].release();
+        alfa_index_free(ix);
+        if (own_host) { alfa_host_index_free(*host); *host = nullptr; }
+        return code;
+    };
+    for (auto& e : ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail_out(alfa::fail(ALFA_EHIP, "hipEventCreate"));
+    const std::string b(prefix);
+    auto open = [&](const char* ext) { FILE* f = fopen((b + ext).c_str(), "rb"); if (f) open_files.push_back(f); return f; };
+    auto count = [&](FILE* f, uint32_t& n) { return fread(&n, 4, 1, f) == 1; };
+    hipStream_t st = cx->stream;
+    if ((rc = upload_padded(ix->S, v->S, (size_t)v->N))) return fail_out(rc);
+    uint32_t n = 0;
+    {
+        FILE* f = open(".sa");
+        if (!f || !count(f, n) || n == 0) return fail_out(alfa::fail(ALFA_EINVAL, "unable to read " + b + ".sa"));
+        if (n >= 0x7fffffffu) return fail_out(alfa::fail(ALFA_EINVAL, "index too large for int32 SA ranks"));
+        if ((rc = stream_file(f, ix->SA, 4 * (size_t)n, 0, st, pin, ev))) return fail_out(rc);
+    }
+    ix->n = n;
+    {
+        FILE* f = open(".lcp");
+        uint32_t nl = 0, nm = 0;
+        if (!f || !count(f, nl) || !count(f, nm) || nl != n) return fail_out(alfa::fail(ALFA_EINVAL, "unable to read " + b + ".lcp"));
+        if ((rc = stream_file(f, ix->LCP, (size_t)nl, 0, st, pin, ev))) return fail_out(rc);
+        std::vector<int64_t> midx(nm);
+        std::vector<int32_t> mval(nm);
+        for (uint32_t i = 0; i < nm; ++i) {
+            struct { uint64_t idx; int32_t val; int32_t pad; } it;      // vec_uchar::item_t on disk (src/sparseSA.h:60-70)
+            if (fread(&it, sizeof(it), 1, f) != 1) return fail_out(alfa::fail(ALFA_EINVAL, b + ".lcp is truncated"));
+            midx[i] = (int64_t)it.idx; mval[i] = it.val;
+        }
+        ix->nM = nm;
+        if ((rc = upload(ix->Midx, midx.data(), 8 * (size_t)nm)) || (rc = upload(ix->Mval, mval.data(), 4 * (size_t)nm))) return fail_out(rc);
+    }
+    ix->has_child = v->has_child; ix->has_suflink = v->has_suflink; ix->has_kmer = v->has_kmer;
+    if (ix->has_child) {
+        FILE* f = open(".child");
+        uint32_t nc = 0;
+        if (!f || !count(f, nc) || nc != n) return fail_out(alfa::fail(ALFA_EINVAL, "unable to read " + b + ".child"));
+        if ((rc = stream_file(f, ix->CHILD, 4 * (size_t)nc, 0, st, pin, ev))) return fail_out(rc);
+    }
+    if (ix->has_suflink) {
+        FILE* f = open(".isa");
+        uint32_t ni = 0;
+        if (!f || !count(f, ni) || ni != n) return fail_out(alfa::fail(ALFA_EINVAL, "unable to read " + b + ".isa"));
+        if ((rc = stream_file(f, ix->ISA, 4 * (size_t)ni, 0, st, pin, ev))) return fail_out(rc);
+    }
+    if (v->n_seq > 0 && v->startpos && (rc = upload(ix->STARTPOS, v->startpos, 8 * (size_t)v->n_seq))) return fail_out(rc);
+    ix->n_seq = (v->n_seq > 0 && v->startpos) ? v->n_seq : 0;
+    {
+        bool seen[256] = {};                                 // (see alfa_index_upload)
+        for (int64_t i = 0; i < v->N; ++i) seen[v->S[i]] = true;
+        for (int c = 1; c < 256 && !ix->nul_sub; ++c)
+            if (!seen[c] && c != 'a' && c != 'c' && c != 'g' && c != 't') ix->nul_sub = (uint8_t)c;
+    }
+    if (ix->has_kmer) {
+        FILE* f = open(".kmer");
+        uint32_t nk = 0;
+        if (!f || !count(f, nk) || nk != TABLE) return fail_out(alfa::fail(ALFA_EINVAL, "unable to read " + b + ".kmer"));
+        std::vector<uint32_t> kmr(2 * (size_t)TABLE), kb(TABLE / 32, 0u);
+        if (fread(kmr.data(), 8, TABLE, f) != TABLE) return fail_out(alfa::fail(ALFA_EINVAL, b + ".kmer is truncated"));
+        size_t nset = 0;
+        for (size_t i = 0; i < TABLE; ++i) {
+            const uint32_t l = kmr[2 * i], r = kmr[2 * i + 1];
+            if (r > 0 && (l > r || r >= n)) return fail_out(alfa::fail(ALFA_EINVAL, "10-mer table entry outside the suffix array (left <= right < n violated)"));
+            if (r > 0) { kb[i >> 5] |= 1u << (i & 31); ++nset; }
+        }
+        ix->kbit_fill = (double)nset / (double)TABLE;
+        if ((rc = upload(ix->KMR, kmr.data(), 8 * (size_t)TABLE)) || (rc = upload(ix->KBIT, kb.data(), TABLE / 8)) ||
+            (rc = ix->KMR2.reserve(16 * (size_t)TABLE + 16))) return fail_out(rc);
+        hipLaunchKernelGGL(kmr2_kernel, dim3(TABLE / 256), dim3(256), 0, st, ix->KMR.as<uint2>(), ix->SA.as<uint32_t>(), ix->S.as<uint8_t>() + PADB,
+                           (int64_t)n, ix->N, ix->KMR2.as<uint4>());
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail_out(alfa::fail(ALFA_EHIP, "kmr2_kernel"));
+    }
+    for (FILE* f : open_files) fclose(f);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    pin[0].release(); pin[1].release();
     *out = ix;
     return ALFA_OK;
 }

@@ -300,6 +300,18 @@ class DeviceIndex:
         check(lib().alfa_index_upload(C.byref(host_index.view), int(device), C.byref(h)))
         self._h = h
 
+    @classmethod
+    def load(cls, prefix, device=0, host_index=None):
+        """index files straight to device memory (alfa_index_load_to_device); the host's share (text, names, offsets) comes
+        back as self.host -- or is taken from `host_index` (a second GPU)"""
+        hh = C.c_void_p(host_index._h.value if host_index is not None else None)
+        h = C.c_void_p()
+        check(lib().alfa_index_load_to_device(prefix.encode(), int(device), C.byref(hh), C.byref(h)))
+        self = cls.__new__(cls)
+        self.host = host_index if host_index is not None else HostIndex(hh)
+        self._h = h
+        return self
+
     def seed_batch(self, mem_type, queries):
         def fn(h, t, q, nq, m, o):
             rc = lib().alfa_seed_batch(h, t, q, nq, m, o)

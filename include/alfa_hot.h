@@ -106,6 +106,13 @@ typedef struct alfa_index alfa_index;   /* opaque; owns the HBM-resident copy on
  * (src/sparseSA.cpp:390-476, 478-558); here they are copied once into HBM
  * (plus derived device layouts) and stay resident. */
 int  alfa_index_upload(const alfa_index_view* host_arrays, int device, alfa_index** out);
+/* replaces: sparseSA::load (src/sparseSA.cpp:390-476) + the upload above for a caller that maps on the GPU (SURVEY 8f item 3,
+ * "direct-to-HBM index loader"): <prefix>.sa / .lcp / .child / .isa go from the files through two pinned staging buffers to
+ * device memory, file reads overlapped with the copies, never through host vectors; the 10-mer table's device companions are
+ * derived on the device.  *host == NULL: the host's share is loaded first (alfa_host_index_load_text) and returned there;
+ * *host != NULL (a second GPU): it is used as it is.  The device copy is the one alfa_index_upload makes, byte for byte. */
+struct alfa_host_index;                  /* include/alfa_index.h */
+int  alfa_index_load_to_device(const char* prefix, int device, struct alfa_host_index** host, alfa_index** out);
 void alfa_index_free(alfa_index*);
 int  alfa_index_device(const alfa_index*);
 

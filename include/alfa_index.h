@@ -34,6 +34,9 @@ int alfa_host_index_build_mem(int n_seq, const char* const* names, const char* c
 /* sparseSA::load: reads <prefix>.aux/.ref/.sa/.lcp/.child/.kmer/.isa as written by the reference.
  * Returns ALFA_EINVAL if <prefix>.aux is missing (the reference returns false -> caller rebuilds). */
 int alfa_host_index_load(const char* prefix, alfa_host_index** out);
+/* the same for a caller whose arrays go straight to device memory (alfa_index_load_to_device, alfa_hot.h): only <prefix>.aux and
+ * .ref are read -- text, sequence names and offsets, what the mapper's host side needs; the view's SA / LCP / CHILD / KMR are null */
+int alfa_host_index_load_text(const char* prefix, alfa_host_index** out);
 /* sparseSA::save: byte-identical files */
 int alfa_host_index_save(const alfa_host_index*, const char* prefix);
 

@@ -91,3 +91,40 @@ def test_cli_gpu_index_files(gpu):
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     for ext, want in G.index_md5()["lambda_K12"].items():
         assert G.md5_file(pre + "." + ext) == want, ext
+
+
+def test_index_files_straight_to_device(gpu, tmp_path):
+    """alfa_index_load_to_device: the arrays go from the files through pinned staging to HBM, the 10-mer companions are derived on
+    the device; the resident copy answers every kind of seed query, and maps whole reads, exactly as the copy alfa_index_upload
+    makes from host arrays -- child-table, suffix-link and no-child / no-kmer indexes, two contigs"""
+    import seqgen
+    from alfalfa_amd import ffi
+    rng = np.random.default_rng(31)
+    seqs = [seqgen.rand_ref(rng, 700000), seqgen.rand_ref(rng, 300000)]
+    text = b"`".join(seqs)
+    reads = []
+    for _ in range(400):
+        p = int(rng.integers(0, len(text) - 400))
+        reads.append(seqgen.mutate(rng, text[p:p + 300].replace(b"`", b"a"), 0.03))
+    for k, (suflink, child, kmer) in enumerate(((False, True, True), (True, True, True), (False, False, False))):
+        hidx = ffi.HostIndex.build_mem(["c1", "c2"], seqs, K=3 if suflink else 12, suflink=suflink, child=child, kmer=kmer)
+        pre = str(tmp_path / ("idx%d" % k))
+        hidx.save(pre)
+        up = ffi.DeviceIndex(hidx, 0)
+        direct = ffi.DeviceIndex.load(pre, 0)
+        assert direct.host.view.N == hidx.view.N and direct.host.view.n_seq == 2 and direct.host.descr(1) == "c2"
+        second = ffi.DeviceIndex.load(pre, 0, host_index=direct.host)          # (a second GPU: the host's share is reused)
+        for mt in (ffi.SEED_SMAM, ffi.SEED_MEM) + ((ffi.SEED_SMEM,) if child else ()):
+            q = ffi.make_seed_queries(reads, 25, 10000, 1)
+            m0, o0 = up.seed_batch(mt, q)
+            for other in (direct, second):
+                m1, o1 = other.seed_batch(mt, q)
+                assert np.array_equal(o0, o1) and np.array_equal(m0, m1), (k, mt)
+        if child and kmer and not suflink:
+            opt = ffi.default_map_options()
+            P = ffi.default_params()
+            mr = ffi.make_map_reads(reads, [seqgen.revcomp(r) for r in reads], 12, opt)
+            for x, y in zip(ffi.map_reads_batch(up, opt, P, mr), ffi.map_reads_batch(direct, opt, P, mr)):
+                assert np.array_equal(x, y)
+    with pytest.raises(ffi.AlfaError):
+        ffi.DeviceIndex.load(str(tmp_path / "nothing_here"), 0)

@@ -27,7 +27,7 @@ for mode in ([], ["--host-trials"]):
     err = p.stderr.decode()
     print(mode, "rc", p.returncode, "%.2f s" % dt, "%.0f reads/s" % (n / dt))
     for l in err.split("\n"):
-        if l.startswith(("#CORE", "#WORKERS", "#PHASES", "#STATS")):
+        if l.startswith(("#CORE", "#WORKERS", "#PHASES", "#STATS", "#STARTUP")):
             print("  ", l[:400])
     calls = [l for l in err.split("\n") if l.startswith("#MAPCALL")]
     for l in calls[:3] + [l for l in calls if int(l.split()[2]) < 200][:12]:
