@@ -24,6 +24,7 @@ python3 tools/rocprof_summary.py pmc "$OUT/fetch" gpurun_out/pmc_fetch_size.csv 
   --note "bytes per dispatch at 100000 reads/step (C3 workload): raw FETCH_SIZE x 1024 (rocprofv3 reports KiB), rocprofv3 --pmc FETCH_SIZE pass; calibration for this access pattern in r01_fetch_calibration.csv (an isolated 4-16 B gather tallies 64 B; streaming reads tally half their bytes)" > /dev/null
 python3 tools/rocprof_summary.py pmc "$OUT/write" gpurun_out/pmc_write_l2.csv --only bench.py > /dev/null
 python3 tools/rocprof_summary.py pmc "$OUT/sq" gpurun_out/pmc_sq.csv --only bench.py > /dev/null
+python3 tools/valu_busy.py gpurun_out/pmc_sq.csv gpurun_out/kernel_trace_stats.csv gpurun_out/valu_busy.json > /dev/null
 python3 tools/seed_limiter.py gpurun_out/pmc_sq.csv gpurun_out/pmc_write_l2.csv gpurun_out/pmc_traffic.json gpurun_out/kernel_trace_stats.csv gpurun_out/seed_limiter.json > /dev/null
 rm -rf "$OUT"/*/      # the raw databases are large; the summaries are what travels back
 # the DP kernels by themselves: the captured C3 task stream (tools/data) x5 = one bench step, every result checked
