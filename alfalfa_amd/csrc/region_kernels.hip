@@ -22,10 +22,15 @@ namespace alfa {
 
 namespace {
 
-constexpr int RCAP = REGION_MATCH_CAP;
-constexpr int RREG = REGION_CAP;
+// Two sizes of the same kernel.  A wavefront's state lives in LDS and its size decides how many strands a CU works on at a time:
+// at 512 matches / 128 regions it is 15.9 KB -- 10 wavefronts per CU, for a kernel that waits on LDS and memory most of its time --
+// while nearly every strand of a short read has a handful of matches.  So strands of up to SMALL_CAP matches run in a 3 KB
+// instance (launched first, for all strands); the full-size instance, launched behind it, takes the strands the small one left:
+// those with more matches, and those whose first chain outgrew the small instance's scratch (status 2 in between).
+constexpr int SMALL_CAP = 64;
 
-struct Lds {
+template <int RCAP, int RREG>
+struct LdsT {
     int64_t R[RCAP];
     int32_t Q[RCAP], L[RCAP];
     uint16_t o1[RCAP], sm[RCAP], rs[RCAP], tmp[RCAP];
@@ -37,17 +42,20 @@ struct Lds {
 
 }  // namespace
 
+template <int RCAP, int RREG, bool SMALL>
 __global__ __launch_bounds__(64) void regions_kernel(const alfa_match* __restrict__ m_all, const int64_t* __restrict__ base,
                                                     const int32_t* __restrict__ qlen, const int32_t* __restrict__ edit, int nq,
                                                     RegionParams rp, alfa_region* __restrict__ reg_out, alfa_match* __restrict__ rm_out,
                                                     int32_t* __restrict__ chain_out,
                                                     int32_t* __restrict__ nreg_out, int32_t* __restrict__ nrm_out, int32_t* __restrict__ status) {
-    __shared__ Lds s;
+    __shared__ LdsT<RCAP, RREG> s;
     const int qi = blockIdx.x, lane = threadIdx.x;
     if (qi >= nq) return;
     const int64_t b0 = base[qi];
     const int64_t nn = base[qi + 1] - b0;
     const int64_t rm_base = 2 * b0 + 8 * (int64_t)qi;          // the strand's slots: n regions at b0, 2n + 8 members here
+    if (SMALL && nn > SMALL_CAP) return;                       // the full-size instance's
+    if (!SMALL && !(nn > SMALL_CAP || status[qi] == 2)) return;      // done by the small instance
     if (nn == 0 || nn > RCAP) {
         if (lane == 0) { nreg_out[qi] = 0; nrm_out[qi] = 0; status[qi] = nn ? 1 : 0; }
         return;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(64) void regions_kernel(const alfa_match* __restric
             }
             s.tmp[rank] = (uint16_t)i;
         }
-        if (fail) s.fail = 1;
+        if (fail) s.fail = 1;                   // (an ambiguity: final, whatever the instance)
         __syncthreads();
         for (int k = lane; k < m; k += 64) {
             const int i = s.tmp[k];
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(64) void regions_kernel(const alfa_match* __restric
                 }
             }
             curEdit += qLB > 0 ? 1 : 0;
-            if (nback > RCAP / 2 || nfwd > RCAP / 2) s.fail = 1;
+            if (nback > RCAP / 2 || nfwd > RCAP / 2) s.fail = SMALL ? 2 : 1;          // (small instance: the full-size one tries again)
             else {
                 int32_t* co = chain_out + rm_base + cursor;
                 int c = 0;
@@ -281,14 +289,17 @@ __global__ __launch_bounds__(64) void regions_kernel(const alfa_match* __restric
         const bool f = bad || s.fail;
         nreg_out[qi] = f ? 0 : nreg;
         nrm_out[qi] = f ? 0 : cursor;
-        status[qi] = f ? 1 : 0;
+        status[qi] = f ? ((SMALL && !bad && s.fail == 2) ? 2 : 1) : 0;
     }
 }
 
 void launch_regions(hipStream_t st, const alfa_match* d_m, const int64_t* d_base, const int32_t* d_qlen, const int32_t* d_edit, int nq,
                     const RegionParams& rp, alfa_region* d_reg, alfa_match* d_rm, int32_t* d_chain, int32_t* d_nreg, int32_t* d_nrm, int32_t* d_status) {
     if (nq <= 0) return;
-    hipLaunchKernelGGL(regions_kernel, dim3(nq), dim3(64), 0, st, d_m, d_base, d_qlen, d_edit, nq, rp, d_reg, d_rm, d_chain, d_nreg, d_nrm, d_status);
+    hipLaunchKernelGGL((regions_kernel<SMALL_CAP, SMALL_CAP, true>), dim3(nq), dim3(64), 0, st, d_m, d_base, d_qlen, d_edit, nq, rp, d_reg, d_rm, d_chain,
+                       d_nreg, d_nrm, d_status);
+    hipLaunchKernelGGL((regions_kernel<REGION_MATCH_CAP, REGION_CAP, false>), dim3(nq), dim3(64), 0, st, d_m, d_base, d_qlen, d_edit, nq, rp, d_reg, d_rm,
+                       d_chain, d_nreg, d_nrm, d_status);
 }
 
 }  // namespace alfa
