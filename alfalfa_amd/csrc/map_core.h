@@ -115,16 +115,18 @@ MC_FN void ins_sort(uint16_t* a, int first, int last, Before before) {   // __in
     }
 }
 template <class Before>
-MC_FN bool sort_like_libstdcxx(uint16_t* a, int n, Before before) {
+MC_FN bool sort_like_libstdcxx(uint16_t* a, int n, uint32_t* stk, int stkCap, Before before) {
     if (n <= 1) return true;
     int lg = 0;
     for (int t = n; t > 1; t >>= 1) ++lg;
-    // __introsort_loop, its recursion on the right part as an explicit stack of (first, last, depth)
-    int stF[48], stL[48], stD[48], sp = 0;
-    stF[0] = 0; stL[0] = n; stD[0] = 2 * lg; sp = 1;
+    // __introsort_loop, its recursion on the right part as an explicit stack of (first, last, depth) in the caller's memory
+    // (stkCap entries of three words; the device build hands over LDS -- an array on the function's own stack is scratch
+    // memory there, the only one the kernel would have).  The depth limit bounds the stack by 2 lg n + 1 entries.
+    int sp = 0;
+    stk[0] = 0; stk[1] = (uint32_t)n; stk[2] = (uint32_t)(2 * lg); sp = 1;
     while (sp > 0) {
         --sp;
-        int first = stF[sp], last = stL[sp], depth = stD[sp];
+        int first = (int)stk[3 * sp], last = (int)stk[3 * sp + 1], depth = (int)stk[3 * sp + 2];
         // the library recurses into [cut, last) FIRST and then loops on [first, cut); partitions of disjoint ranges commute,
         // so the order in which the two parts are processed does not change the result
         while (last - first > 16) {
@@ -148,8 +150,8 @@ MC_FN bool sort_like_libstdcxx(uint16_t* a, int n, Before before) {
                 ++lo;
             }
             const int cut = lo;
-            if (sp >= 48) return false;
-            stF[sp] = cut; stL[sp] = last; stD[sp] = depth; ++sp;
+            if (sp >= stkCap) return false;
+            stk[3 * sp] = (uint32_t)cut; stk[3 * sp + 1] = (uint32_t)last; stk[3 * sp + 2] = (uint32_t)depth; ++sp;
             last = cut;
         }
     }
@@ -518,7 +520,7 @@ MC_FN int map_read(Env& env, Work& W, const Options& O, const ReadParams& R, int
     if (nRegions > REGION_CAP2) { W.fail = 3; return NEED_CALLER; }
     for (int k = 0; k < nRegions; ++k) W.rorder[k] = (uint16_t)k;
     const int32_t* sc = W.rscore;
-    if (!sort_like_libstdcxx(W.rorder, nRegions, [sc](uint16_t x, uint16_t y) { return sc[x] > sc[y]; })) { W.fail = 4; return NEED_CALLER; }   // compIntervals :1114
+    if (!sort_like_libstdcxx(W.rorder, nRegions, W.bam, BAM_CAP / 3, [sc](uint16_t x, uint16_t y) { return sc[x] > sc[y]; })) { W.fail = 4; return NEED_CALLER; }   // compIntervals :1114
     if (nRegions == 0) return DONE;                          // :1272: no regions, no rescue
     if (!O.rescueOnly) {
         run_regions(env, W, O, R, nRegions, O.maxAlnCount, R.minCoverage, R.minScore);

@@ -49,7 +49,8 @@ static int sort_selftest() {
             const int32_t* kp = key.data();
             auto before = [kp](uint16_t u, uint16_t v) { return kp[u] > kp[v]; };
             std::sort(a.begin(), a.end(), before);
-            if (!alfa::mapcore::sort_like_libstdcxx(b.data(), n, before)) { printf("depth limit hit at n=%d\n", n); return 1; }
+            uint32_t stk[alfa::mapcore::BAM_CAP];                  // (the stack map_read hands over: BAM_CAP / 3 entries)
+            if (!alfa::mapcore::sort_like_libstdcxx(b.data(), n, stk, alfa::mapcore::BAM_CAP / 3, before)) { printf("depth limit hit at n=%d\n", n); return 1; }
             if (a != b) { printf("order differs at n=%d rep=%d\n", n, rep); return 1; }
             ++cases;
         }

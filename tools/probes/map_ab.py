@@ -16,6 +16,8 @@ if os.environ.get("MAP_AB_CHILD") != "1":
         sys.exit(p.returncode)
     ms = [float(x) for x in re.findall(r"map_kernel_ms ([0-9.]+)", p.stderr)]
     print("%-28s %s  map_kernel_ms %s  %s" % (os.path.basename(sys.argv[1]), sys.argv[2], " ".join("%.2f" % x for x in ms), p.stdout.strip()))
+    if os.environ.get("MAP_AB_VERBOSE"):
+        print("   " + [l for l in p.stderr.splitlines() if l.startswith("#MAPCALL")][-1])
     sys.exit(0)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
