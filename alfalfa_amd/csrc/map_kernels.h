@@ -34,6 +34,7 @@ struct MapKernelArgs {
     // *next until none is left, so the scratch is sized by what the GPU holds at a time, not by the batch)
     int32_t slots;
     int32_t* next;                  // the next read to take; 0 at launch
+    const int32_t* order;           // the order in which the reads are taken (longest first: the last ones to start are short), or null
     int32_t* reasons;               // [16] diagnostics: reads handed back, by cause (map_kernel's reason codes); 0 at launch
     uint8_t* scratch;               // slots of scratch_stride bytes: nt4 query and target of the task in flight
     int32_t scratch_stride, qcap;   // a slot holds a query of up to qcap bytes at 16 and a target behind it

@@ -301,8 +301,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         __syncthreads();
         if (ln == 0) next_read = atomicAdd(A.next, 1);
         __syncthreads();
-        const int r = next_read;
-        if (r >= A.n) break;
+        if (next_read >= A.n) break;
+        const int r = A.order ? A.order[next_read] : next_read;
         const int sf = 2 * r, sr = 2 * r + 1;
         const int64_t bf = A.base[sf], br = A.base[sr], be = A.base[sr + 1];
         int status = mapcore::DONE, naln = 0, nseed = 0, nops = 0;

@@ -500,6 +500,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     const bool devmap = o.aln.deviceMap && ops[0].map_reads_batch && !o.aln.noFW && !o.aln.noRC && !o.aln.coreTrials && !o.aln.deviceRegions &&
                         (o.pair1.empty() || o.paired.mode == 1);
     const size_t readCap = (size_t)T * (size_t)std::max(256, devmap ? std::max(o.fibers, o.mapBatch) : o.fibers);
+    const int minSlice = std::max(1, getenv("ALFA_MIN_SLICE") ? atoi(getenv("ALFA_MIN_SLICE")) : 4096);      // reads per device call at least (long reads)
     const bool direct_render = getenv("ALFA_NO_DIRECT_RENDER") == nullptr;       // (the general path for every read: A/B runs and tests)
 
     struct Batch {
@@ -562,10 +563,14 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 Batch* B = bp.release();
                 const int n = B->n;
                 B->seq = seq++;
-                B->text.assign((size_t)T, std::string());
-                B->cnt.assign((size_t)T * 4, 0);
-                B->remaining.store(T);
-                for (int k = 0; k < T; ++k) slices.push(Slice{B, k, (int)((int64_t)n * k / T), (int)((int64_t)n * (k + 1) / T)});
+                // a slice is one device call: long reads fill a batch's base budget with few reads, and T calls of a thousand
+                // reads each neither fill the GPU (a call lasts as long as its longest read, whatever else it holds) nor get
+                // along on the four hardware queues they share -- fewer, larger slices then (minSlice reads at least)
+                const int K = devmap ? std::max(1, std::min(T, n / minSlice)) : T;
+                B->text.assign((size_t)K, std::string());
+                B->cnt.assign((size_t)K * 4, 0);
+                B->remaining.store(K);
+                for (int k = 0; k < K; ++k) slices.push(Slice{B, k, (int)((int64_t)n * k / K), (int)((int64_t)n * (k + 1) / K)});
             }
             { std::lock_guard<std::mutex> g(dm); n_dispatched = seq; }
             dcv.notify_all();
@@ -584,7 +589,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 }
                 double t0 = now();
                 total += B->n;
-                for (int t = 0; t < T; ++t) {
+                for (size_t t = 0; t < B->cnt.size() / 4; ++t) {
                     mapped1 += B->cnt[t * 4]; printed1 += B->cnt[t * 4 + 1]; mapped2 += B->cnt[t * 4 + 2]; printed2 += B->cnt[t * 4 + 3];
                 }
                 for (const std::string& s : B->text)

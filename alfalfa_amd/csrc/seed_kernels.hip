@@ -34,6 +34,8 @@
 #include <atomic>
 #include <cstdlib>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -54,6 +56,16 @@ struct alfa_index {
     alfa::DevBuf S, SA, LCP, Midx, Mval, CHILD, KMR, KMR2, KBIT, ISA;
     alfa::DevBuf STARTPOS;   // start offsets of the concatenated sequences (chromosome bounds for the mapping kernel)
     int n_seq = 0;
+    // alfa_map_reads_batch on long reads: the direction bytes of the ksw_global calls of the reads in flight take gigabytes (a
+    // slot per resident workgroup, sized for the longest read of the call).  Calls on this index share ZPOOL such buffers
+    // instead of every calling thread keeping its own: the GPU runs four kernels side by side at most (its hardware queues),
+    // and sixteen threads' worth of such buffers is memory the driver has to clear when the process ends -- long enough for
+    // the next process to stall behind it.  A call takes a buffer for the time of its map_kernel.
+    static constexpr int ZPOOL = 3;
+    std::mutex zmu;
+    std::condition_variable zcv;
+    alfa::DevBuf zbuf[ZPOOL];
+    bool zbusy[ZPOOL] = {false, false, false};
 };
 
 namespace {
@@ -1900,6 +1912,7 @@ void alfa_index_free(alfa_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     ix->S.release(); ix->SA.release(); ix->LCP.release(); ix->Midx.release(); ix->Mval.release(); ix->CHILD.release(); ix->KMR.release(); ix->KMR2.release(); ix->KBIT.release(); ix->ISA.release(); ix->STARTPOS.release();
+    for (alfa::DevBuf& b : ix->zbuf) b.release();
     delete ix;
 }
 
@@ -2509,13 +2522,15 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     const size_t nints = (size_t)n + 6 * ((size_t)n + 1) + 16;        // (+ 16 words of diagnostics: A.reasons)              // status[n] | naln | nseed | nops | aln_off | seed_off | op_off, n+1 each (int32)
     // scratch of a read in flight, per workgroup of the launch: its staged strings, the direction bytes of its ksw_global call
     // (the whole read at 256 bytes per row: every piece fits) and the BAM operations of that call's walk.  The launch has as
-    // many workgroups as the GPU keeps resident -- fewer when the slots would exceed 4 GiB (reads beyond ~5 kbp)
+    // many workgroups as the GPU keeps resident -- fewer when the slots would exceed 8 GiB per calling thread (reads beyond
+    // ~10 kbp; ALFA_MAP_ZSCRATCH_GIB changes the bound)
     const int64_t zworst = 256 * ((int64_t)max_plen + max_edit + 8);
     const int bam_cap = max_plen + max_edit + 8;
     const int64_t zstride = o->cigar_alignments > 0 ? zworst : 0;
     const int64_t zslot = o->cigar_alignments > 0 ? ((zstride + 4 * (int64_t)bam_cap + 255) & ~(int64_t)255) : 0;
     int slots = std::min(n, alfa::map_resident_workgroups());
-    if (zslot > 0) slots = (int)std::max<int64_t>(1, std::min<int64_t>(slots, std::max<int64_t>(256, ((int64_t)4 << 30) / zslot)));
+    static const int64_t zscratch_gib = [] { const char* e = getenv("ALFA_MAP_ZSCRATCH_GIB"); const int v = e ? atoi(e) : 8; return (int64_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
+    if (zslot > 0) slots = (int)std::max<int64_t>(1, std::min<int64_t>(slots, std::max<int64_t>(256, (zscratch_gib << 30) / zslot)));
     size_t tmp_bytes = 0;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int32_t*)nullptr, (int32_t*)nullptr, n + 1, st));
     // ONE device arena and ONE pinned arena per calling thread for everything below (each hipMalloc / hipHostMalloc is a trip
@@ -2523,7 +2538,7 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     size_t dsz = 0;
     auto carve = [&](size_t bytes) { const size_t at = dsz; dsz += (bytes + 255) & ~(size_t)255; return at; };
     const size_t o_rp = carve(sizeof(alfa::mapcore::ReadParams) * (size_t)n), o_off = carve(8 * ((size_t)nq + 1)), o_prm = carve(sizeof(DevParams));
-    const size_t o_int = carve(4 * (nints + 8)), o_tmp = carve(tmp_bytes + 64);
+    const size_t o_int = carve(4 * (nints + 8)), o_tmp = carve(tmp_bytes + 64), o_ord = carve(4 * (size_t)n);
     const size_t o_aln = carve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP), o_aln2 = carve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP);
     const size_t o_seed = carve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP), o_seed2 = carve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP);
     // a read's extended CIGAR: at 10 % error about one operation per five residues per reported alignment; room for one per two
@@ -2532,12 +2547,18 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
                             ? (int)std::max<int64_t>(OPS_CAP, std::min<int64_t>((int64_t)max_plen / 2 + 64, ((int64_t)256 << 20) / (8 * (int64_t)n)))
                             : OPS_CAP;
     const size_t o_ops = carve(sizeof(alfa::mapcore::CigOp) * (size_t)n * (size_t)ops_cap), o_ops2 = carve(sizeof(alfa::mapcore::CigOp) * (size_t)n * (size_t)ops_cap);
-    const size_t o_scr = carve((size_t)stride64 * (size_t)slots + 64), o_z = carve((size_t)zslot * (size_t)slots + 64);
+    const size_t zbytes = (size_t)zslot * (size_t)slots + 64;
+    const bool zshared = zbytes > ((size_t)1 << 30);           // long reads: one of the index's shared buffers (alfa_index::zbuf)
+    const size_t o_scr = carve((size_t)stride64 * (size_t)slots + 64), o_z = carve(zshared ? 64 : zbytes);
     // pinned: [ReadParams n | DevParams | strand offsets 2n+1 | the int block] ; the dense results are staged in a second pinned buffer
     size_t hsz = 0;
     auto hcarve = [&](size_t bytes) { const size_t at = hsz; hsz += (bytes + 63) & ~(size_t)63; return at; };
     const size_t p_rp = hcarve(sizeof(alfa::mapcore::ReadParams) * (size_t)n), p_prm = hcarve(sizeof(DevParams)), p_off = hcarve(8 * ((size_t)nq + 1));
     const size_t p_int = hcarve(4 * (nints + 8));
+    // reads of very different lengths (long-read data): the longest first, so that what the workgroups take last is short --
+    // a call ends when its last read does
+    const bool by_length = max_plen >= 1000;
+    const size_t p_ord = hcarve(by_length ? 4 * (size_t)n : 0);
     if ((rc = pl->d_marena.reserve(dsz)) || (rc = pl->h_mint.reserve(hsz))) return rc;
     char* const dA = pl->d_marena.as<char>();
     char* const hA = pl->h_mint.as<char>();
@@ -2554,6 +2575,12 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
         ALFA_HIP(hipMemcpyAsync(dA + o_rp, hA + p_rp, sizeof(alfa::mapcore::ReadParams) * (size_t)n, hipMemcpyHostToDevice, st));
         ALFA_HIP(hipMemcpyAsync(dA + o_prm, hA + p_prm, sizeof(DevParams), hipMemcpyHostToDevice, st));
         ALFA_HIP(hipMemcpyAsync(dA + o_off, hA + p_off, 8 * (size_t)nq, hipMemcpyHostToDevice, st));
+        if (by_length) {
+            int32_t* ho = (int32_t*)(hA + p_ord);
+            for (int i = 0; i < n; ++i) ho[i] = i;
+            std::stable_sort(ho, ho + n, [reads](int32_t a, int32_t b) { return reads[a].plen > reads[b].plen; });
+            ALFA_HIP(hipMemcpyAsync(dA + o_ord, ho, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+        }
     }
     int32_t* d_int = (int32_t*)(dA + o_int);
     int32_t* d_status = d_int;
@@ -2571,6 +2598,7 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     A.nreg = d_aux + 2 * (size_t)nq; A.rstatus = d_aux + 4 * (size_t)nq;
     A.dp_params = dA + o_prm; A.scratch = (uint8_t*)(dA + o_scr); A.scratch_stride = (int32_t)stride64; A.qcap = qcap;
     A.zscratch = (uint8_t*)(dA + o_z); A.zstride = zstride; A.zslot = zslot; A.bam_cap = bam_cap;
+    A.order = by_length ? (const int32_t*)(dA + o_ord) : nullptr;
     A.slots = slots; A.next = d_int + nints; A.reasons = d_int + nints - 16;          // (the int block has 8 spare words behind its arrays; all zeroed below)
     A.opt.cigarCount = o->cigar_alignments > 0 ? o->cigar_alignments : 0; A.opt.rescueOnly = o->rescue_only ? 1 : 0;
     A.opt.match = o->match; A.opt.mismatch = o->mismatch; A.opt.openGap = o->open_gap; A.opt.extendGap = o->extend_gap;
@@ -2578,6 +2606,31 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     A.opt.maxAlnCount = o->max_aln_count; A.opt.rescue = o->rescue; A.opt.errorPercent = o->error_percent;
     A.status = d_status; A.naln = d_naln; A.nseed = d_nseed; A.nops = d_nops;
     A.alns = (alfa::mapcore::AlnOut*)(dA + o_aln); A.seeds = (alfa_match*)(dA + o_seed); A.ops = (alfa::mapcore::CigOp*)(dA + o_ops); A.ops_cap = ops_cap;
+    struct ZHold {           // the shared buffer, from the kernel's launch until the host has seen the call's results
+        alfa_index* ix; int k = -1;
+        void release() {
+            if (k < 0) return;
+            { std::lock_guard<std::mutex> g(ix->zmu); ix->zbusy[k] = false; }
+            ix->zcv.notify_one();
+            k = -1;
+        }
+        ~ZHold() { release(); }
+    } zhold{ix};
+    if (zshared) {
+        {
+            std::unique_lock<std::mutex> g(ix->zmu);
+            int k = -1;
+            ix->zcv.wait(g, [&] {
+                for (int j = 0; j < alfa_index::ZPOOL && k < 0; ++j) if (!ix->zbusy[j] && ix->zbuf[j].cap >= zbytes) k = j;     // one that is large enough already
+                for (int j = 0; j < alfa_index::ZPOOL && k < 0; ++j) if (!ix->zbusy[j]) k = j;
+                return k >= 0;
+            });
+            ix->zbusy[k] = true;
+            zhold.k = k;
+        }
+        if ((rc = ix->zbuf[zhold.k].reserve(zbytes))) return rc;
+        A.zscratch = ix->zbuf[zhold.k].as<uint8_t>();
+    }
     ALFA_HIP(hipEventRecord(pl->mev0, st));
     alfa::launch_map(st, A);
     ALFA_HIP(hipGetLastError());
@@ -2599,6 +2652,7 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     ALFA_HIP(hipMemcpyAsync(h_int, d_int, 4 * nints, hipMemcpyDeviceToHost, st));
     const double ms_enq = since(tc0) - ms_fill - ms_seeds;
     ALFA_HIP(hipStreamSynchronize(st));
+    zhold.release();
     const double ms_map = since(tc0) - ms_fill - ms_seeds - ms_enq;
     const int32_t* h_status = h_int;
     const int32_t* h_aoff = h_int + n + 3 * ((size_t)n + 1);
@@ -2638,9 +2692,13 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
         for (int k = 1; k <= 11; ++k) fprintf(stderr, " %d", why[k]);
         fprintf(stderr, "\n");
     }
-    if (call_log)
-        fprintf(stderr, "#MAPCALL reads %d matches %lld alns %lld fill_ms %.3f seeds_ms %.3f enqueue_ms %.3f regions_map_wait_ms %.3f total_ms %.3f map_kernel_ms %.3f seed_kernel_ms %.3f\n",
-                n, (long long)total, (long long)ta, ms_fill, ms_seeds, ms_enq, ms_map, since(tc0), ms, alfa_seed_plan_kernel_ms(pl));
+    if (call_log) {
+        size_t mfree = 0, mtotal = 0;
+        (void)hipMemGetInfo(&mfree, &mtotal);
+        fprintf(stderr, "#MAPCALL reads %d matches %lld alns %lld fill_ms %.3f seeds_ms %.3f enqueue_ms %.3f regions_map_wait_ms %.3f total_ms %.3f map_kernel_ms %.3f seed_kernel_ms %.3f arena_mb %.0f zscratch_mb %.0f prefixes %lld device_used_mb %.0f\n",
+                n, (long long)total, (long long)ta, ms_fill, ms_seeds, ms_enq, ms_map, since(tc0), ms, alfa_seed_plan_kernel_ms(pl), dsz / 1048576.0, zbytes / 1048576.0,
+                (long long)pl->total_pref, (mtotal - mfree) / 1048576.0);
+    }
     return ALFA_OK;
 }
 

@@ -13,7 +13,7 @@ for l in open(sys.argv[1]):
     f = l.split()[1:]
     d = {f[i]: float(f[i + 1]) for i in range(0, len(f) - 1, 2)}
     rows.append(d)
-    for k, v in d.items(): tot[k] = tot.get(k, 0) + v
+    for k, v in d.items(): tot[k] = max(tot.get(k, 0), v) if k.endswith("_mb") else tot.get(k, 0) + v
     n += 1
 print("calls", n, " sums:", "  ".join("%s %.1f" % kv for kv in tot.items()))
 rows.sort(key=lambda d: -d["total_ms"])
