@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <map>
 #include <charconv>
+#include <immintrin.h>
 #include <type_traits>
 
 namespace alfa {
@@ -1178,6 +1179,29 @@ void Mapper::map_batch(Read* const* reads, int n, std::vector<uint8_t>& done) {
     g_map_us[2] += (long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
 }
 
+// The two strands of a read sixteen residues at a time: lower case, and the complement of a / c / g / t / n out of a table
+// indexed by the low four bits of the letter (1, 3, 7, 4, 14: all different), reversed into place.  Stops in front of the first
+// block that holds anything else (IUPAC codes, other bytes) or does not fill sixteen bytes; returns how far it came -- the
+// caller's byte loop, which is the definition, does the rest.
+__attribute__((target("ssse3"))) static int strands_ssse3(const unsigned char* s, int len, char* fw, char* rc) {
+    const __m128i loA = _mm_set1_epi8('A' - 1), hiZ = _mm_set1_epi8('Z' + 1), bit5 = _mm_set1_epi8(32), nib = _mm_set1_epi8(15);
+    //                                 0    1    2    3    4    5    6    7    8    9    10   11   12   13   14   15
+    const __m128i comp = _mm_setr_epi8(0, 't', 0, 'g', 'a', 0, 0, 'c', 0, 0, 0, 0, 0, 0, 'n', 0);
+    const __m128i self = _mm_setr_epi8(1, 'a', 0, 'c', 't', 0, 0, 'g', 0, 0, 0, 0, 0, 0, 'n', 0);      // (no byte equals the entry of its own low bits elsewhere)
+    const __m128i rev = _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+    int k = 0;
+    for (; k + 16 <= len; k += 16) {
+        const __m128i c = _mm_loadu_si128((const __m128i*)(s + k));
+        const __m128i upper = _mm_and_si128(_mm_cmpgt_epi8(c, loA), _mm_cmpgt_epi8(hiZ, c));
+        const __m128i lower = _mm_add_epi8(c, _mm_and_si128(upper, bit5));
+        const __m128i idx = _mm_and_si128(lower, nib);
+        if (_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_shuffle_epi8(self, idx), lower)) != 0xffff) break;
+        _mm_storeu_si128((__m128i*)(fw + k), lower);
+        _mm_storeu_si128((__m128i*)(rc + len - 16 - k), _mm_shuffle_epi8(_mm_shuffle_epi8(comp, idx), rev));
+    }
+    return k;
+}
+
 void Mapper::map_raw(const RawRead* raw, int n, std::vector<std::unique_ptr<MapCallResult>>& calls, std::vector<RawResult>& res) {
     res.assign((size_t)n, RawResult());
     if (n <= 0) return;
@@ -1187,12 +1211,14 @@ void Mapper::map_raw(const RawRead* raw, int n, std::vector<std::unique_ptr<MapC
     size_t total = 0;
     for (int i = 0; i < n; ++i) { strandOff_[(size_t)i] = total; rawLen_[(size_t)i] = raw[i].len; total += 2 * (size_t)raw[i].len; }
     if (strands_.size() < total) strands_.resize(total);
+    static const bool ssse3 = __builtin_cpu_supports("ssse3");
     for (int i = 0; i < n; ++i) {
         const int len = raw[i].len;
         char* fw = &strands_[strandOff_[(size_t)i]];
         char* rc = fw + len;
         const unsigned char* s = (const unsigned char*)raw[i].seq;
-        for (int k = 0; k < len; ++k) {      // tolower in the "C" locale (the reader, src/fasta.cpp:147), then read_t::init's reverse complement
+        int k = ssse3 ? strands_ssse3(s, len, fw, rc) : 0;
+        for (; k < len; ++k) {      // tolower in the "C" locale (the reader, src/fasta.cpp:147), then read_t::init's reverse complement
             const unsigned char c = (unsigned char)(s[k] + ((unsigned char)(s[k] - 'A') < 26u ? 32 : 0));
             fw[k] = (char)c;
             rc[len - 1 - k] = RC.t[c];

@@ -2056,7 +2056,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
             int t = e ? atoi(e) : (int)std::min<unsigned>(8, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));
             return t < 1 ? 1 : (t > 32 ? 32 : t);
         }();
-        const int nt = nq >= 32768 ? std::min(pack_threads, nq / 8192) : 1;
+        const int nt = nq >= 65536 ? std::min(pack_threads, nq / 8192) : 1;       // (the mapper's slices: 32 768 strands per call, sixteen callers)
         std::vector<Part> parts((size_t)std::max(nt, 1));
         if (nt <= 1) pack_range(0, nq, parts[0]);
         else {
