@@ -1202,19 +1202,19 @@ __attribute__((target("ssse3"))) static int strands_ssse3(const unsigned char* s
     return k;
 }
 
-void Mapper::map_raw(const RawRead* raw, int n, std::vector<std::unique_ptr<MapCallResult>>& calls, std::vector<RawResult>& res) {
+void Mapper::map_raw(const RawRead* raw, int n, RawStrands& S, std::vector<std::unique_ptr<MapCallResult>>& calls, std::vector<RawResult>& res) {
     res.assign((size_t)n, RawResult());
     if (n <= 0) return;
     const auto tm0 = std::chrono::steady_clock::now();
-    strandOff_.resize((size_t)n);
-    rawLen_.resize((size_t)n);
+    S.off.resize((size_t)n);
+    S.len.resize((size_t)n);
     size_t total = 0;
-    for (int i = 0; i < n; ++i) { strandOff_[(size_t)i] = total; rawLen_[(size_t)i] = raw[i].len; total += 2 * (size_t)raw[i].len; }
-    if (strands_.size() < total) strands_.resize(total);
+    for (int i = 0; i < n; ++i) { S.off[(size_t)i] = total; S.len[(size_t)i] = raw[i].len; total += 2 * (size_t)raw[i].len; }
+    if (S.bytes.size() < total) S.bytes.resize(total);
     static const bool ssse3 = __builtin_cpu_supports("ssse3");
     for (int i = 0; i < n; ++i) {
         const int len = raw[i].len;
-        char* fw = &strands_[strandOff_[(size_t)i]];
+        char* fw = &S.bytes[S.off[(size_t)i]];
         char* rc = fw + len;
         const unsigned char* s = (const unsigned char*)raw[i].seq;
         int k = ssse3 ? strands_ssse3(s, len, fw, rc) : 0;
@@ -1248,7 +1248,7 @@ void Mapper::map_raw(const RawRead* raw, int n, std::vector<std::unique_ptr<MapC
         rd_.resize(who.size());
         for (size_t k = 0; k < who.size(); ++k) {
             const int i = who[k];
-            describe(strand(i, false), strand(i, true), raw[i].len, rd_[k], r2 ? 2.0 * opt_.errorPercent : opt_.errorPercent, memStage);
+            describe(S.strand(i, false), S.strand(i, true), raw[i].len, rd_[k], r2 ? 2.0 * opt_.errorPercent : opt_.errorPercent, memStage);
         }
         g_map_us[0] += (long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - td0).count();
         calls.emplace_back(new MapCallResult());
@@ -1289,7 +1289,7 @@ inline char* put_int(char* p, long v) {
 }
 }  // namespace
 
-void Mapper::render_direct(const RawRead& rr, int i, const RawResult& rs, std::string& out, long* mappedPrinted) {
+void Mapper::render_direct(const RawStrands& S, const RawRead& rr, int i, const RawResult& rs, std::string& out, long* mappedPrinted) const {
     const int len = rr.len;
     const size_t at = out.size();
     const MapCallResult& R = *rs.R;
@@ -1300,7 +1300,7 @@ void Mapper::render_direct(const RawRead& rr, int i, const RawResult& rs, std::s
         memcpy(p, rr.name, (size_t)rr.nameLen); p += rr.nameLen;
         static const char mid[] = "\t4\t*\t0\t0\t*\t*\t0\t0\t";
         memcpy(p, mid, sizeof(mid) - 1); p += sizeof(mid) - 1;
-        memcpy(p, strand(i, false), (size_t)len); p += len;
+        memcpy(p, S.strand(i, false), (size_t)len); p += len;
         *p++ = '\t';
         memcpy(p, rr.qual, (size_t)len); p += len;
         *p++ = '\n';
@@ -1342,7 +1342,7 @@ void Mapper::render_direct(const RawRead& rr, int i, const RawResult& rs, std::s
     if (run > 0) { p = put_int(p, run); *p++ = 'M'; }
     static const char mid[] = "\t*\t0\t0\t";
     memcpy(p, mid, sizeof(mid) - 1); p += sizeof(mid) - 1;
-    memcpy(p, strand(i, rc), (size_t)len); p += len;
+    memcpy(p, S.strand(i, rc), (size_t)len); p += len;
     *p++ = '\t';
     if (rc) { for (int k = 0; k < len; ++k) p[k] = rr.qual[len - 1 - k]; }
     else memcpy(p, rr.qual, (size_t)len);

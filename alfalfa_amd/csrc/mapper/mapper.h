@@ -122,6 +122,14 @@ struct MapCallResult {
 
 // where a read's final result lies after map_raw's rounds: entry j of one of the calls, or nowhere (unmapped after the last round)
 struct RawResult { const MapCallResult* R = nullptr; int j = 0; bool unmapped = false; };
+// the lower-cased reads and their reverse complements map_raw made (the calls' P / Prc point into it): stays with whoever
+// renders the results, which need not be the thread that made the calls
+struct RawStrands {
+    std::vector<char> bytes;
+    std::vector<size_t> off;
+    std::vector<int> len;
+    const char* strand(int i, bool rc) const { return bytes.data() + off[(size_t)i] + (rc ? len[(size_t)i] : 0); }
+};
 
 struct RefIndex {                 // the parts of `sparseSA` the mapper itself touches
     const alfa_host_index* h = nullptr;
@@ -153,11 +161,10 @@ class Mapper {
     // reads -- then goes from there straight to its SAM line (render_direct: read_t::postprocess src/mapper.cpp:322-358 and
     // printUnpairedAlignment src/mapper.h:181-193 for that case, no read_t / alignment_t objects in between); every other
     // read is materialised and takes the general path (adopt() gives it the call's alignments when it has them)
-    void map_raw(const RawRead* raw, int n, std::vector<std::unique_ptr<MapCallResult>>& calls, std::vector<RawResult>& res);
-    const char* strand(int i, bool rc) const { return strands_.data() + strandOff_[(size_t)i] + (rc ? rawLen_[(size_t)i] : 0); }
+    void map_raw(const RawRead* raw, int n, RawStrands& S, std::vector<std::unique_ptr<MapCallResult>>& calls, std::vector<RawResult>& res);
     bool direct_ok(const RawResult& rs) const;
     bool device_done(const RawResult& rs) const { return rs.unmapped || rs.R->st[(size_t)rs.j] == 0; }
-    void render_direct(const RawRead& rr, int i, const RawResult& rs, std::string& out, long* mappedPrinted);
+    void render_direct(const RawStrands& S, const RawRead& rr, int i, const RawResult& rs, std::string& out, long* mappedPrinted) const;
     void adopt(Read& r, const MapCallResult& R, int i);
     void map_unpaired_rest(Read& read, bool done);      // what is left of map_unpaired after map_batch: (unpaired_match,) postprocess
     bool finish_unpaired_direct(Read& read);            // ... for a read whose CIGARs came with its alignments: no fiber needed; false = needs one
@@ -222,9 +229,6 @@ class Mapper {
     const PairedOpt& popt_;
     HotSched& hot_;
     std::vector<alfa_map_read> rd_;       // reused from call to call
-    std::vector<char> strands_;
-    std::vector<size_t> strandOff_;
-    std::vector<int> rawLen_;
 };
 
 std::string sam_header(const RefIndex& idx, int argc, char** argv);

@@ -501,6 +501,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                         (o.pair1.empty() || o.paired.mode == 1);
     const size_t readCap = (size_t)T * (size_t)std::max(256, devmap ? std::max(o.fibers, o.mapBatch) : o.fibers);
     const int minSlice = std::max(1, getenv("ALFA_MIN_SLICE") ? atoi(getenv("ALFA_MIN_SLICE")) : 4096);      // reads per device call at least (long reads)
+    const int groupReads = std::max(64, getenv("ALFA_GROUP_READS") ? atoi(getenv("ALFA_GROUP_READS")) : 8192);   // long reads: reads per group call
     const bool direct_render = getenv("ALFA_NO_DIRECT_RENDER") == nullptr;       // (the general path for every read: A/B runs and tests)
 
     struct Batch {
@@ -521,6 +522,19 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         std::vector<long> cnt;                // per slice: mapped1, printed1, mapped2, printed2
         std::atomic<int> remaining{0};        // slices still being worked on
         long seq = 0;                         // position in the input
+        // long reads: the batch is cut into a few groups of thousands of reads, ONE worker maps a group in one device call (a
+        // call lasts as long as its longest read whatever else it holds, and only a call of many reads keeps the GPU full),
+        // then all workers render the group's slices from these results
+        struct Group {                        // reads [lo, hi) of the batch, mapped by one worker in one call (+ the rescue rounds' calls)
+            int lo = 0, hi = 0;
+            bool mapped = false;
+            std::vector<RawRead> raw;
+            RawStrands strands;
+            std::vector<std::unique_ptr<MapCallResult>> calls;
+            std::vector<RawResult> res;
+        };
+        std::vector<std::unique_ptr<Group>> groups;
+        int ngroups = 0;                      // groups in use (0: the batch goes to the workers slice by slice)
     };
     typedef std::unique_ptr<Batch> BatchP;
     long total = 0, mapped1 = 0, mapped2 = 0, printed1 = 0, printed2 = 0;
@@ -529,15 +543,61 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
     // fill(batch) -> false at end of input; work(batch, t, k, lo, hi) maps and renders reads [lo,hi) = slice k of the batch on worker t
-    auto stream = [&](const std::function<bool(Batch&)>& fill, const std::function<void(Batch&, int, int, int, int)>& work) {
+    // whole(batch, g, t): optional -- maps group g of the batch on worker t when it can (Group::mapped); work() of its slices then only renders
+    auto stream = [&](const std::function<bool(Batch&)>& fill, const std::function<void(Batch&, int, int, int, int, int)>& work,
+                      const std::function<void(Batch&, int, int)>& whole = nullptr) {
         // batches circulate reader -> dispatcher -> workers -> writer -> reader, so that the reads' strings are allocated once.
         // A batch is cut into T slices that the workers take from one queue, with no barrier between batches: the workers drift
         // apart, so that while some wait for the GPU (one device call per slice) the others build reads or render SAM, instead
         // of all T calls arriving at the GPU at once and all T renderings leaving it idle.  The writer takes finished batches
         // in input order.
-        struct Slice { Batch* B; int k, lo, hi; };
+        struct Slice { Batch* B; int k, lo, hi, g; };        // g: the group whose call holds the reads' results, or -1
         Chan<BatchP> parsed(2), spare(8);
-        Chan<Slice> slices((size_t)2 * (size_t)T);
+        // what the workers take: slices (from the dispatcher, at most 2 T waiting; from a worker that has mapped a group,
+        // without a bound -- a worker never waits here) and groups to map (at most T waiting, taken first: they feed the GPU)
+        struct WorkQ {
+            std::mutex mu;
+            std::condition_variable cv;
+            std::deque<Slice> q;
+            std::deque<std::pair<Batch*, int>> wholes;
+            size_t cap = 0;
+            int wholes_running = 0;
+            bool closed = false;
+            void push(Slice sl) {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return q.size() < cap; });
+                q.push_back(sl);
+                cv.notify_all();
+            }
+            void push_whole(Batch* B, int grp) {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return wholes.size() < cap; });
+                wholes.emplace_back(B, grp);
+                cv.notify_all();
+            }
+            void whole_done(const std::vector<Slice>& sl) {
+                std::lock_guard<std::mutex> g(mu);
+                for (const Slice& x : sl) q.push_back(x);
+                --wholes_running;
+                cv.notify_all();
+            }
+            void close() {
+                std::lock_guard<std::mutex> g(mu);
+                closed = true;
+                cv.notify_all();
+            }
+            // 1: a slice, 2: a group to map, 0: nothing will come any more
+            int pop(Slice& sl, std::pair<Batch*, int>& W) {
+                std::unique_lock<std::mutex> g(mu);
+                for (;;) {
+                    if (!wholes.empty()) { W = wholes.front(); wholes.pop_front(); ++wholes_running; cv.notify_all(); return 2; }
+                    if (!q.empty()) { sl = q.front(); q.pop_front(); cv.notify_all(); return 1; }
+                    if (closed && wholes_running == 0) return 0;
+                    cv.wait(g);
+                }
+            }
+        } slices;
+        slices.cap = (size_t)2 * (size_t)T;
         std::mutex dm;
         std::condition_variable dcv;
         std::map<long, Batch*> finished;
@@ -567,10 +627,26 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 // reads each neither fill the GPU (a call lasts as long as its longest read, whatever else it holds) nor get
                 // along on the four hardware queues they share -- fewer, larger slices then (minSlice reads at least)
                 const int K = devmap ? std::max(1, std::min(T, n / minSlice)) : T;
+                B->ngroups = 0;
+                if (whole && K < T) {          // few reads for its bases: long reads
+                    const int G = std::max(1, std::min(T, (n + groupReads / 2) / groupReads));
+                    const int R = (T + G - 1) / G;                  // slices a group is rendered in
+                    while ((int)B->groups.size() < G) B->groups.emplace_back(new Batch::Group());
+                    B->ngroups = G;
+                    B->text.assign((size_t)G * R, std::string());
+                    B->cnt.assign((size_t)G * R * 4, 0);
+                    B->remaining.store(G * R);
+                    for (int g = 0; g < G; ++g) {
+                        B->groups[(size_t)g]->lo = (int)((int64_t)n * g / G);
+                        B->groups[(size_t)g]->hi = (int)((int64_t)n * (g + 1) / G);
+                        slices.push_whole(B, g);
+                    }
+                    continue;
+                }
                 B->text.assign((size_t)K, std::string());
                 B->cnt.assign((size_t)K * 4, 0);
                 B->remaining.store(K);
-                for (int k = 0; k < K; ++k) slices.push(Slice{B, k, (int)((int64_t)n * k / K), (int)((int64_t)n * (k + 1) / K)});
+                for (int k = 0; k < K; ++k) slices.push(Slice{B, k, (int)((int64_t)n * k / K), (int)((int64_t)n * (k + 1) / K), -1});
             }
             { std::lock_guard<std::mutex> g(dm); n_dispatched = seq; }
             dcv.notify_all();
@@ -604,9 +680,21 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         const double tm0 = now();
         pool.run([&](int t) {
             Slice sl;
-            while (slices.pop(sl)) {
-                work(*sl.B, t, sl.k, sl.lo, sl.hi);
+            std::pair<Batch*, int> wg;
+            for (int kind; (kind = slices.pop(sl, wg)) != 0;) {
+                if (kind == 2) {
+                    Batch* wb = wg.first;
+                    const int g = wg.second, G = wb->ngroups, R = (T + G - 1) / G;
+                    whole(*wb, g, t);
+                    const int lo = wb->groups[(size_t)g]->lo, n = wb->groups[(size_t)g]->hi - lo;
+                    std::vector<Slice> cut((size_t)R);
+                    for (int k = 0; k < R; ++k) cut[(size_t)k] = Slice{wb, g * R + k, lo + (int)((int64_t)n * k / R), lo + (int)((int64_t)n * (k + 1) / R), g};
+                    slices.whole_done(cut);
+                    continue;
+                }
+                work(*sl.B, t, sl.k, sl.lo, sl.hi, sl.g);
                 if (sl.B->remaining.fetch_sub(1) == 1) {
+                    for (int g = 0; g < sl.B->ngroups; ++g) sl.B->groups[(size_t)g]->calls.clear();          // (freed on a worker: the writer only writes)
                     { std::lock_guard<std::mutex> g(dm); finished[sl.B->seq] = sl.B; }
                     dcv.notify_all();
                 }
@@ -639,26 +727,34 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 }
                 return B.n > 0;
             },
-            [&](Batch& B, int t, int k, int lo, int hi) {
+            [&](Batch& B, int t, int k, int lo, int hi, int grp) {
                 Mapper& mp = *mappers[t];
                 std::string& txt = B.text[(size_t)k];
                 long* c = &B.cnt[(size_t)k * 4];
                 const double tb0 = now();
-                bool raw_ok = direct_render && mp.device_map_usable();
-                for (int i = lo; i < hi && raw_ok; i++) raw_ok = B.ra[i].p != nullptr;
+                const Batch::Group* GR = grp >= 0 && B.groups[(size_t)grp]->mapped ? B.groups[(size_t)grp].get() : nullptr;
+                bool raw_ok = GR || (direct_render && mp.device_map_usable());
+                for (int i = lo; i < hi && raw_ok && !GR; i++) raw_ok = B.ra[i].p != nullptr;
                 if (raw_ok) {
                     // records the reader only split go to the device as they are; a read that comes back finished, with at most
                     // one alignment and its CIGAR, is rendered straight from the call's results -- no Read, no Alignment objects
                     const int n = hi - lo;
-                    static thread_local std::vector<RawRead> raw;
-                    raw.resize((size_t)n);
-                    for (int i = 0; i < n; i++) raw[(size_t)i] = raw_read(B.ra[lo + i]);
+                    static thread_local std::vector<RawRead> raw_own;
+                    static thread_local RawStrands strands_own;
                     std::vector<std::unique_ptr<MapCallResult>> calls;
-                    std::vector<RawResult> res;
+                    std::vector<RawResult> res_own;
                     const double td0 = now();
-                    mp.map_raw(raw.data(), n, calls, res);
-                    const double td1 = now();
-                    w_dev[t] += td1 - td0;
+                    if (!GR) {
+                        raw_own.resize((size_t)n);
+                        for (int i = 0; i < n; i++) raw_own[(size_t)i] = raw_read(B.ra[lo + i]);
+                        mp.map_raw(raw_own.data(), n, strands_own, calls, res_own);
+                        w_dev[t] += now() - td0;
+                    }
+                    // the slice's reads in the call's arrays: the group's (read lo of the batch is entry lo - GR->lo) or this slice's own
+                    const int sbase = GR ? lo - GR->lo : 0;
+                    const RawRead* raw = GR ? GR->raw.data() + sbase : raw_own.data();
+                    const RawResult* res = GR ? GR->res.data() + sbase : res_own.data();
+                    const RawStrands& strands = GR ? GR->strands : strands_own;
                     std::vector<uint8_t> direct((size_t)n);
                     std::vector<int> rest;
                     std::vector<uint8_t> done((size_t)n);
@@ -681,7 +777,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                     for (int i = 0; i < n; i++) {
                         if (direct[(size_t)i]) {
                             const long before = c[0];
-                            mp.render_direct(raw[(size_t)i], i, res[(size_t)i], txt, c);
+                            mp.render_direct(strands, raw[(size_t)i], sbase + i, res[(size_t)i], txt, c);
                             with_cigar += c[0] - before;
                             continue;
                         }
@@ -732,6 +828,24 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                     }
                     r.release();          // on the worker: the writer thread only writes
                 }
+            },
+            [&](Batch& B, int grp, int t) {
+                // a group of long reads through the device in one call (and the rescue rounds' calls) on this worker
+                Mapper& mp = *mappers[t];
+                Batch::Group& G = *B.groups[(size_t)grp];
+                G.mapped = false;
+                G.calls.clear();
+                if (!direct_render || !mp.device_map_usable() || getenv("ALFA_NO_GROUP_CALLS")) return;
+                const int n = G.hi - G.lo;
+                for (int i = 0; i < n; i++)
+                    if (!B.ra[G.lo + i].p) return;
+                const double td0 = now();
+                G.raw.resize((size_t)n);
+                for (int i = 0; i < n; i++) G.raw[(size_t)i] = raw_read(B.ra[G.lo + i]);
+                mp.map_raw(G.raw.data(), n, G.strands, G.calls, G.res);
+                const double td1 = now();
+                w_dev[t] += td1 - td0; w_run[t] += td1 - td0;
+                G.mapped = true;
             });
         printf("sequences read: %ld\nsequences mapped: %ld\nalignments printed: %ld\n", total, mapped1, printed1);
     }
@@ -762,7 +876,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 }
                 return B.n > 0;
             },
-            [&](Batch& B, int t, int k, int lo, int hi) {
+            [&](Batch& B, int t, int k, int lo, int hi, int) {
                 Mapper& mp = *mappers[t];
                 std::string& txt = B.text[(size_t)k];
                 long* c = &B.cnt[(size_t)k * 4];

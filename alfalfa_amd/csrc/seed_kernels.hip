@@ -2056,7 +2056,10 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
             int t = e ? atoi(e) : (int)std::min<unsigned>(8, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));
             return t < 1 ? 1 : (t > 32 ? 32 : t);
         }();
-        const int nt = nq >= 65536 ? std::min(pack_threads, nq / 8192) : 1;       // (the mapper's slices: 32 768 strands per call, sixteen callers)
+        // (the mapper's slices of short reads: 32 768 strands = 8 MB per call, sixteen callers at once: one thread each; its
+        // whole-batch calls of long reads: 50 000 strands = 300 MB from one caller)
+        const int nt = nq >= 65536 ? std::min(pack_threads, nq / 8192)
+                                   : (bytes >= ((size_t)64 << 20) && nq >= 64) ? std::min<int>(pack_threads, (int)(bytes >> 24)) : 1;
         std::vector<Part> parts((size_t)std::max(nt, 1));
         if (nt <= 1) pack_range(0, nq, parts[0]);
         else {
@@ -2542,9 +2545,9 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     const size_t o_aln = carve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP), o_aln2 = carve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP);
     const size_t o_seed = carve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP), o_seed2 = carve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP);
     // a read's extended CIGAR: at 10 % error about one operation per five residues per reported alignment; room for one per two
-    // residues (more: op_count = -1 for that alignment, the caller recovers it), within 256 MiB per call
+    // residues (more: op_count = -1 for that alignment, the caller recovers it), within 2 GiB per call (x 2: slotted and dense)
     const int ops_cap = o->cigar_alignments > 0
-                            ? (int)std::max<int64_t>(OPS_CAP, std::min<int64_t>((int64_t)max_plen / 2 + 64, ((int64_t)256 << 20) / (8 * (int64_t)n)))
+                            ? (int)std::max<int64_t>(OPS_CAP, std::min<int64_t>((int64_t)max_plen / 2 + 64, ((int64_t)2 << 30) / (8 * (int64_t)n)))
                             : OPS_CAP;
     const size_t o_ops = carve(sizeof(alfa::mapcore::CigOp) * (size_t)n * (size_t)ops_cap), o_ops2 = carve(sizeof(alfa::mapcore::CigOp) * (size_t)n * (size_t)ops_cap);
     const size_t zbytes = (size_t)zslot * (size_t)slots + 64;

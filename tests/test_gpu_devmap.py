@@ -209,10 +209,12 @@ def test_cli_device_path_equals_host_trials_and_counts(gpu):
                 m = re.search(r"#CORE reads_done (\d+) handed_back (\d+)", p.stderr.decode())
                 assert m and int(m.group(1)) > 2000, (extra, m and m.group(0))
         assert outs[0] == outs[1], extra
-    # the same reads through the general formatter (read / alignment objects for every read) and with one device call at a time:
-    # the direct renderer and the barrier-free slices change nothing in the output
+    # the same reads through the general formatter (read / alignment objects for every read), with one device call at a time, with
+    # every slice making its own call instead of rendering from a group's call, and with groups of 64 reads (many per batch):
+    # the direct renderer, the barrier-free slices and the group calls change nothing in the output
     base = None
-    for env in ({}, {"ALFA_NO_DIRECT_RENDER": "1"}, {"ALFA_MAP_LANES": "1"}):
+    for env in ({}, {"ALFA_NO_DIRECT_RENDER": "1"}, {"ALFA_MAP_LANES": "1"}, {"ALFA_NO_GROUP_CALLS": "1"}, {"ALFA_GROUP_READS": "64"},
+                {"ALFA_GROUP_READS": "64", "ALFA_MIN_SLICE": "1"}):
         out = os.path.join(d, "devmap_env.sam")
         p = subprocess.run([M.GPU_EXE, "align", "-i", pre, "-0", "synse.fq", "-o", out, "-t", "5", "--map-batch", "300"], cwd=d,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
