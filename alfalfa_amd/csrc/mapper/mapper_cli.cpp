@@ -554,7 +554,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         struct Slice { Batch* B; int k, lo, hi, g; };        // g: the group whose call holds the reads' results, or -1
         Chan<BatchP> parsed(2), spare(8);
         // what the workers take: slices (from the dispatcher, at most 2 T waiting; from a worker that has mapped a group,
-        // without a bound -- a worker never waits here) and groups to map (at most T waiting, taken first: they feed the GPU)
+        // without a bound -- a worker never waits here) and groups to map (at most 2 T waiting)
         struct WorkQ {
             std::mutex mu;
             std::condition_variable cv;
@@ -590,8 +590,10 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
             int pop(Slice& sl, std::pair<Batch*, int>& W) {
                 std::unique_lock<std::mutex> g(mu);
                 for (;;) {
-                    if (!wholes.empty()) { W = wholes.front(); wholes.pop_front(); ++wholes_running; cv.notify_all(); return 2; }
+                    // slices first: what a finished call returned is rendered (and written) while other workers' calls run --
+                    // groups first would leave every rendering and the writer's whole work for the end of the input
                     if (!q.empty()) { sl = q.front(); q.pop_front(); cv.notify_all(); return 1; }
+                    if (!wholes.empty()) { W = wholes.front(); wholes.pop_front(); ++wholes_running; cv.notify_all(); return 2; }
                     if (closed && wholes_running == 0) return 0;
                     cv.wait(g);
                 }
