@@ -164,6 +164,7 @@ def run_cli(exe, index_prefix, fq, out, threads, extra=(), gpus=None, stats=Fals
     env.pop("GPU_MAX_HW_QUEUES", None)
     if _ORIG_HWQ is not None:
         env["GPU_MAX_HW_QUEUES"] = _ORIG_HWQ
+    os.sync()          # what this script wrote just before (the FASTQ, the C4 block's files) leaves the page cache's dirty list first
     with GpuBusy() as gb:
         t0 = time.perf_counter()
         pr = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
