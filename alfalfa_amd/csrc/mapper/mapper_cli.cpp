@@ -439,6 +439,13 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         return 0;
     }
     const int T = std::max(1, o.threads);
+    // -t counts the threads the tool keeps busy: beside the workers there are the reader and the writer thread, each busy for
+    // most of a run of short reads (the reference's -t workers stand still while its main thread reads and writes).  From
+    // eight threads on, two of them are those: at most T - 2 workers build reads / render SAM at a time (device calls for a
+    // group of long reads, which wait for the GPU, are not counted).  On a box that gives the process exactly -t cores,
+    // sixteen busy workers plus the two were slower than fourteen plus the two: 4 000 000 short reads 0.62-0.65 s against
+    // 0.53-0.55 s (ALFA_WORKERS sets the number)
+    const int busyWorkers = getenv("ALFA_WORKERS") ? std::max(1, atoi(getenv("ALFA_WORKERS"))) : (T >= 8 ? T - 2 : T);
     const int G = std::max(1, o.gpus);
     std::vector<HotOps> ops((size_t)G);
     // A saved index goes straight from its files to the GPUs when the binding can do that (the arrays never pass through host
@@ -562,6 +569,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
             std::deque<std::pair<Batch*, int>> wholes;
             size_t cap = 0;
             int wholes_running = 0;
+            int slices_running = 0, slices_max = 1;
             bool closed = false;
             void push(Slice sl) {
                 std::unique_lock<std::mutex> g(mu);
@@ -586,20 +594,26 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 closed = true;
                 cv.notify_all();
             }
+            void slice_done() {
+                std::lock_guard<std::mutex> g(mu);
+                --slices_running;
+                cv.notify_all();
+            }
             // 1: a slice, 2: a group to map, 0: nothing will come any more
             int pop(Slice& sl, std::pair<Batch*, int>& W) {
                 std::unique_lock<std::mutex> g(mu);
                 for (;;) {
                     // slices first: what a finished call returned is rendered (and written) while other workers' calls run --
                     // groups first would leave every rendering and the writer's whole work for the end of the input
-                    if (!q.empty()) { sl = q.front(); q.pop_front(); cv.notify_all(); return 1; }
+                    if (!q.empty() && slices_running < slices_max) { sl = q.front(); q.pop_front(); ++slices_running; cv.notify_all(); return 1; }
                     if (!wholes.empty()) { W = wholes.front(); wholes.pop_front(); ++wholes_running; cv.notify_all(); return 2; }
-                    if (closed && wholes_running == 0) return 0;
+                    if (closed && wholes_running == 0 && q.empty()) return 0;
                     cv.wait(g);
                 }
             }
         } slices;
         slices.cap = (size_t)2 * (size_t)T;
+        slices.slices_max = busyWorkers;
         std::mutex dm;
         std::condition_variable dcv;
         std::map<long, Batch*> finished;
@@ -695,6 +709,7 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                     continue;
                 }
                 work(*sl.B, t, sl.k, sl.lo, sl.hi, sl.g);
+                slices.slice_done();
                 if (sl.B->remaining.fetch_sub(1) == 1) {
                     for (int g = 0; g < sl.B->ngroups; ++g) sl.B->groups[(size_t)g]->calls.clear();          // (freed on a worker: the writer only writes)
                     { std::lock_guard<std::mutex> g(dm); finished[sl.B->seq] = sl.B; }
