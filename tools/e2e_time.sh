@@ -2,7 +2,7 @@
 # GPU box: end-to-end C3 run (4 000 000 reads, 16 workers) three times, with the shell's clock around it
 cd ${GRAFT_REPO_ROOT:-.}
 [ -f /tmp/e2e_c3b/reads.fq ] || timeout -k 10 300 python3 tools/e2e_bench.py --reads 4000000 --threads 16 --exe gpu --dir /tmp/e2e_c3b > /dev/null 2>&1 || exit 1
-EXE=alfalfa_amd/alfalfa_amd
+EXE=${EXE:-alfalfa_amd/alfalfa_amd}
 export ALFA_TEARDOWN_CLOCK=1
 for rep in 1 2 3; do
   rm -f /tmp/e2e_c3b/o.sam
