@@ -66,6 +66,7 @@ struct ReadParams {                 // derived on the host from the read length 
 struct Trial { int64_t refB, refE; int32_t qB, qE; };
 struct ExtRes { int32_t score, qle, tle, gtle, gscore, max_off; };      // = alfa_extend_result
 struct AlnOut { int64_t refB, refE; int32_t qB, qE, score, fw, chainFirst, chainCount, opFirst, opCount, editDist, pad_; };
+struct ChainSeed { int64_t ref; int32_t q, len; };       // = alfa_match
 struct CigOp { int32_t len, code; };            // code: the operation's character ('=', 'X', 'I', 'D', 'S'); len as the reference prints it
 
 struct Work {                       // one read's state (LDS on the device)
@@ -82,8 +83,9 @@ struct Work {                       // one read's state (LDS on the device)
     uint16_t rorder[REGION_CAP2];
     int32_t rscore[REGION_CAP2];
     AlnOut alns[ALN_CAP];                           // the read's alignments, in the order the reference appends them
-    int64_t cref[CHAINOUT_CAP];                     // their chains' seeds
-    int32_t cq[CHAINOUT_CAP], cl[CHAINOUT_CAP];
+    ChainSeed* chain;                               // their chains' seeds, CHAINOUT_CAP of them: memory of the environment's (the device
+                                                    // build: the read's slot of the call's output -- written when an alignment is
+                                                    // accepted, read once per piece when its CIGAR is made; 1.5 KB that LDS does not hold)
     CigOp* ops;                                     // the read's extended CIGAR operations (caller's memory: written, never read back)
     int32_t opsCap;
     uint32_t bam[BAM_CAP];
@@ -353,7 +355,8 @@ MC_FN int try_region(Env& env, Work& W, const Options& O, const ReadParams& R, i
                 W.alns[W.nAln] = o;
                 for (int c = 0; c < chainLen; ++c) {
                     const int k = chain_at(W, a, nBack, c);
-                    W.cref[W.nChainOut + c] = W.mref[k]; W.cq[W.nChainOut + c] = W.mq[k]; W.cl[W.nChainOut + c] = W.ml[k];
+                    ChainSeed cs; cs.ref = W.mref[k]; cs.q = W.mq[k]; cs.len = W.ml[k];
+                    W.chain[W.nChainOut + c] = cs;
                 }
                 W.nChainOut += chainLen;
                 W.nAln += 1;
@@ -451,38 +454,42 @@ MC_FN bool cigar_one(Env& env, Work& W, const Options& O, const ReadParams& R, A
     a.opFirst = W.nOps;
     if (a.qB && !push_op(W, a.qB, 'S')) return false;
     const int c0 = a.chainFirst, cn = a.chainCount;
-    if (W.cq[c0] > a.qB) {
-        const int qLen = W.cq[c0] - a.qB, refLen = (int)(W.cref[c0] - a.refB);
+    // (the chain lies in the environment's memory: every seed is read once, the next one a piece ahead of its use)
+    ChainSeed cur = W.chain[c0];
+    if (cur.q > a.qB) {
+        const int qLen = cur.q - a.qB, refLen = (int)(cur.ref - a.refB);
         const int band = band_estimate(O.fixedBandSize, qLen, refLen, O.match, O.openGap, O.extendGap, a.score);
         if (!dp_piece(env, W, fw, a.qB, qLen, a.refB, refLen, band, edit)) return false;
     }
-    if (!push_op(W, W.cl[c0], '=')) return false;
+    if (!push_op(W, cur.len, '=')) return false;
+    ChainSeed nxt = cn > 1 ? W.chain[c0 + 1] : cur;
     for (int i = 1; i < cn; ++i) {
-        const int p = c0 + i - 1, c = c0 + i;
-        int qDist = W.cq[c] - (W.cq[p] + W.cl[p] - 1);
-        int refDist = (int)(W.cref[c] - (W.cref[p] + W.cl[p] - 1));
+        const ChainSeed prv = cur;
+        cur = nxt;
+        if (i + 1 < cn) nxt = W.chain[c0 + i + 1];
+        int qDist = cur.q - (prv.q + prv.len - 1);
+        int refDist = (int)(cur.ref - (prv.ref + prv.len - 1));
         if (qDist < 0 || refDist < 0) {
             if (qDist >= refDist) qDist -= refDist; else refDist -= qDist;
         }
         bool ok = true;
-        if (qDist <= 0) { ok = push_op(W, refDist, 'D') && push_op(W, W.cl[c] - 1 + qDist, '='); edit += refDist; }
-        else if (refDist <= 0) { ok = push_op(W, qDist, 'I') && push_op(W, W.cl[c] - 1 + refDist, '='); edit += qDist; }
-        else if (qDist == 1) { ok = push_op(W, refDist - 1, 'D') && push_op(W, W.cl[c], '='); edit += refDist - 1; }
-        else if (refDist == 1) { ok = push_op(W, qDist - 1, 'I') && push_op(W, W.cl[c], '='); edit += qDist - 1; }
-        else if (refDist == 2 && qDist == 2) { ok = push_op(W, 1, 'X') && push_op(W, W.cl[c], '='); edit += 1; }
+        if (qDist <= 0) { ok = push_op(W, refDist, 'D') && push_op(W, cur.len - 1 + qDist, '='); edit += refDist; }
+        else if (refDist <= 0) { ok = push_op(W, qDist, 'I') && push_op(W, cur.len - 1 + refDist, '='); edit += qDist; }
+        else if (qDist == 1) { ok = push_op(W, refDist - 1, 'D') && push_op(W, cur.len, '='); edit += refDist - 1; }
+        else if (refDist == 1) { ok = push_op(W, qDist - 1, 'I') && push_op(W, cur.len, '='); edit += qDist - 1; }
+        else if (refDist == 2 && qDist == 2) { ok = push_op(W, 1, 'X') && push_op(W, cur.len, '='); edit += 1; }
         else {
-            const int qLen = W.cq[c] - 1 - (W.cq[p] + W.cl[p]) + 1;
-            const int refLen = (int)(W.cref[c] - 1 - (W.cref[p] + W.cl[p]) + 1);
+            const int qLen = cur.q - 1 - (prv.q + prv.len) + 1;
+            const int refLen = (int)(cur.ref - 1 - (prv.ref + prv.len) + 1);
             const int band = band_estimate(O.fixedBandSize, qLen, refLen, O.match, O.openGap, O.extendGap, a.score);
-            ok = dp_piece(env, W, fw, W.cq[p] + W.cl[p], qLen, W.cref[p] + W.cl[p], refLen, band, edit) && push_op(W, W.cl[c], '=');
+            ok = dp_piece(env, W, fw, prv.q + prv.len, qLen, prv.ref + prv.len, refLen, band, edit) && push_op(W, cur.len, '=');
         }
         if (!ok) return false;
     }
-    const int l = c0 + cn - 1;
-    if (W.cq[l] + W.cl[l] - 1 < a.qE) {
-        const int qLen = a.qE - (W.cq[l] + W.cl[l]) + 1, refLen = (int)(a.refE - (W.cref[l] + W.cl[l]) + 1);
+    if (cur.q + cur.len - 1 < a.qE) {
+        const int qLen = a.qE - (cur.q + cur.len) + 1, refLen = (int)(a.refE - (cur.ref + cur.len) + 1);
         const int band = band_estimate(O.fixedBandSize, qLen, refLen, O.match, O.openGap, O.extendGap, a.score);
-        if (!dp_piece(env, W, fw, W.cq[l] + W.cl[l], qLen, W.cref[l] + W.cl[l], refLen, band, edit)) return false;
+        if (!dp_piece(env, W, fw, cur.q + cur.len, qLen, cur.ref + cur.len, refLen, band, edit)) return false;
     }
     if (R.plen - 1 - a.qE && !push_op(W, R.plen - 1 - a.qE, 'S')) return false;
     a.opCount = W.nOps - a.opFirst;

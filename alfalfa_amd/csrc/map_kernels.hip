@@ -45,7 +45,7 @@ __device__ unsigned long long g_map_prof[16];     // 0 stage, 1 ksw_nw, 2 ksw_ex
 #endif
 
 constexpr int SEQ_OFF = 16;        // wave_task's 8-byte windows may start a few bytes in front of a sequence
-constexpr int ZTILE = 4096;        // direction bytes of a ksw_global call that fit here stay in LDS, rows packed to the band's width
+constexpr int ZTILE = 2048;        // direction bytes of a ksw_global call that fit here stay in LDS, rows packed to the band's width
 
 // Every member function is inlined by force: one that is left as a call takes the DevEnv by address, which puts it -- and the
 // copy of the kernel's arguments it refers to -- into scratch memory, a round trip to HBM for every field the trial loop
@@ -291,7 +291,7 @@ struct DevEnv {
     }
 };
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void map_kernel(const MapKernelArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void map_kernel(const MapKernelArgs A) {
     __shared__ Work W;
     __shared__ __align__(16) uint8_t ztile[ZTILE];
     __shared__ int next_read;
@@ -320,6 +320,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             if (nreg > mapcore::REGION_CAP2) { status = mapcore::NEED_CALLER; why = 3; }
             else {
                 for (int k = ln; k < nreg; k += 64) W.rscore[k] = k < env.nF ? env.regF[k].score : env.regR[k - env.nF].score;
+                static_assert(sizeof(mapcore::ChainSeed) == sizeof(alfa_match), "ChainSeed == alfa_match");
+                W.chain = (mapcore::ChainSeed*)(A.seeds + (int64_t)r * mapcore::CHAINOUT_CAP);      // straight into the read's slot of the output
                 W.ops = A.ops + (int64_t)r * A.ops_cap;          // (every lane stores the same values)
                 W.opsCap = A.ops_cap;
                 W.bamp = W.bam;
@@ -339,10 +341,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                     naln = W.nAln; nseed = W.nChainOut; nops = W.nOps;
                     __syncthreads();
                     for (int k = ln; k < naln; k += 64) A.alns[(int64_t)r * mapcore::ALN_CAP + k] = W.alns[k];
-                    for (int k = ln; k < nseed; k += 64) {
-                        alfa_match m; m.ref = W.cref[k]; m.query = W.cq[k]; m.len = W.cl[k];
-                        A.seeds[(int64_t)r * mapcore::CHAINOUT_CAP + k] = m;
-                    }
                 }
             }
         }
@@ -407,7 +405,7 @@ void launch_map_offsets(hipStream_t st, int n1, const int32_t* a, const int32_t*
     hipLaunchKernelGGL(map_offsets_kernel, dim3(3), dim3(1024), 0, st, n1, a, b, c, oa, ob, oc);
 }
 
-// 3 wavefronts per SIMD (the kernel's registers) and the LDS of a CU both allow 12 one-wave workgroups per CU
+// 4 wavefronts per SIMD (128 registers) and the LDS of a CU (10 KB per workgroup) both allow 16 one-wave workgroups per CU
 int map_resident_workgroups() {
     static const int v = [] {
         int dev = 0, cus = 256;
@@ -415,7 +413,7 @@ int map_resident_workgroups() {
             hipDeviceProp_t p;
             if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
         }
-        return cus * 12;
+        return cus * 16;
     }();
     return v;
 }

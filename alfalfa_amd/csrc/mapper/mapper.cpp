@@ -812,6 +812,8 @@ bool Mapper::core_trials(Read& read, const std::vector<Lis>& lis) {
     std::unique_ptr<mapcore::Work> W(new mapcore::Work());
     std::vector<mapcore::CigOp> opbuf((size_t)std::max<size_t>(mapcore::OPS_CAP, read.sequence.length() + 64));
     W->ops = opbuf.data(); W->opsCap = (int32_t)opbuf.size();
+    std::vector<mapcore::ChainSeed> chainbuf((size_t)mapcore::CHAINOUT_CAP);
+    W->chain = chainbuf.data();
     if (lis.size() > (size_t)mapcore::REGION_CAP2) return false;
     for (size_t k = 0; k < lis.size(); ++k) W->rscore[k] = lis[k].score;
     const mapcore::Options O = core_options(opt_);
@@ -824,7 +826,7 @@ bool Mapper::core_trials(Read& read, const std::vector<Lis>& lis) {
         if (!o.fw) a->flag |= 1u << 4;
         a->refLength = (int)(o.refE - o.refB + 1);
         a->chain.resize((size_t)o.chainCount);
-        for (int c = 0; c < o.chainCount; ++c) a->chain[(size_t)c] = Match{W->cref[o.chainFirst + c], W->cq[o.chainFirst + c], W->cl[o.chainFirst + c]};
+        for (int c = 0; c < o.chainCount; ++c) a->chain[(size_t)c] = Match{W->chain[o.chainFirst + c].ref, W->chain[o.chainFirst + c].q, W->chain[o.chainFirst + c].len};
         if (o.opCount >= 0) { a->ops.assign(W->ops + o.opFirst, W->ops + o.opFirst + o.opCount); a->haveOps = true; a->opsEdit = o.editDist; }
         read.alignments.push_back(a);
     }

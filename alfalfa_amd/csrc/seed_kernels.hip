@@ -57,15 +57,16 @@ struct alfa_index {
     alfa::DevBuf STARTPOS;   // start offsets of the concatenated sequences (chromosome bounds for the mapping kernel)
     int n_seq = 0;
     // alfa_map_reads_batch on long reads: the direction bytes of the ksw_global calls of the reads in flight take gigabytes (a
-    // slot per resident workgroup, sized for the longest read of the call).  Calls on this index share ZPOOL such buffers
+    // slot per resident workgroup, sized for the longest read of the call).  Calls on this index share a few such buffers
     // instead of every calling thread keeping its own: the GPU runs four kernels side by side at most (its hardware queues),
     // and sixteen threads' worth of such buffers is memory the driver has to clear when the process ends -- long enough for
     // the next process to stall behind it.  A call takes a buffer for the time of its map_kernel.
-    static constexpr int ZPOOL = 3;
+    static constexpr int ZPOOL = 8;          // at most; zpool of them are used (ALFA_MAP_ZPOOL, default 4: one per hardware queue)
+    int zpool = [] { const char* e = getenv("ALFA_MAP_ZPOOL"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v > ZPOOL ? ZPOOL : v; }();
     std::mutex zmu;
     std::condition_variable zcv;
     alfa::DevBuf zbuf[ZPOOL];
-    bool zbusy[ZPOOL] = {false, false, false};
+    bool zbusy[ZPOOL] = {false, false, false, false, false, false, false, false};
 };
 
 namespace {
@@ -2525,14 +2526,14 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     const size_t nints = (size_t)n + 6 * ((size_t)n + 1) + 16;        // (+ 16 words of diagnostics: A.reasons)              // status[n] | naln | nseed | nops | aln_off | seed_off | op_off, n+1 each (int32)
     // scratch of a read in flight, per workgroup of the launch: its staged strings, the direction bytes of its ksw_global call
     // (the whole read at 256 bytes per row: every piece fits) and the BAM operations of that call's walk.  The launch has as
-    // many workgroups as the GPU keeps resident -- fewer when the slots would exceed 8 GiB per calling thread (reads beyond
+    // many workgroups as the GPU keeps resident -- fewer when the slots would exceed 12 GiB per call (reads beyond
     // ~10 kbp; ALFA_MAP_ZSCRATCH_GIB changes the bound)
     const int64_t zworst = 256 * ((int64_t)max_plen + max_edit + 8);
     const int bam_cap = max_plen + max_edit + 8;
     const int64_t zstride = o->cigar_alignments > 0 ? zworst : 0;
     const int64_t zslot = o->cigar_alignments > 0 ? ((zstride + 4 * (int64_t)bam_cap + 255) & ~(int64_t)255) : 0;
     int slots = std::min(n, alfa::map_resident_workgroups());
-    static const int64_t zscratch_gib = [] { const char* e = getenv("ALFA_MAP_ZSCRATCH_GIB"); const int v = e ? atoi(e) : 8; return (int64_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
+    static const int64_t zscratch_gib = [] { const char* e = getenv("ALFA_MAP_ZSCRATCH_GIB"); const int v = e ? atoi(e) : 12; return (int64_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();
     if (zslot > 0) slots = (int)std::max<int64_t>(1, std::min<int64_t>(slots, std::max<int64_t>(256, (zscratch_gib << 30) / zslot)));
     size_t tmp_bytes = 0;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int32_t*)nullptr, (int32_t*)nullptr, n + 1, st));
@@ -2624,8 +2625,8 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
             std::unique_lock<std::mutex> g(ix->zmu);
             int k = -1;
             ix->zcv.wait(g, [&] {
-                for (int j = 0; j < alfa_index::ZPOOL && k < 0; ++j) if (!ix->zbusy[j] && ix->zbuf[j].cap >= zbytes) k = j;     // one that is large enough already
-                for (int j = 0; j < alfa_index::ZPOOL && k < 0; ++j) if (!ix->zbusy[j]) k = j;
+                for (int j = 0; j < ix->zpool && k < 0; ++j) if (!ix->zbusy[j] && ix->zbuf[j].cap >= zbytes) k = j;     // one that is large enough already
+                for (int j = 0; j < ix->zpool && k < 0; ++j) if (!ix->zbusy[j]) k = j;
                 return k >= 0;
             });
             ix->zbusy[k] = true;

@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU box: the C4 end-to-end run with ALFA_CALL_LOG=1, its #MAPCALL lines (one per alfa_map_reads_batch call) summed per field
 cd ${GRAFT_REPO_ROOT:-.}
-D=/tmp/e2e_c4b
-[ -f $D/reads.fq ] || timeout -k 10 500 python3 tools/e2e_bench.py --reads 50000 --threads 16 --exe gpu --ref-len 100000000 --long --err 0.1 --extra=-e\ 0.12 --index-with gpu --dir $D > /dev/null 2>&1 || exit 1
+D=${D:-/tmp/e2e_c4b}
+[ -f $D/reads.fq ] || timeout -k 10 500 python3 tools/e2e_bench.py --reads ${NREADS:-50000} --threads 16 --exe gpu --ref-len 100000000 --long --err 0.1 --extra=-e\ 0.12 --index-with gpu --dir $D > /dev/null 2>&1 || exit 1
 ALFA_CALL_LOG=1 timeout -k 10 100 alfalfa_amd/alfalfa_amd align -i $D/idx12 -0 $D/reads.fq -o $D/o.sam -t 16 -e 0.12 --stats "$@" 2> $D/err.txt > /dev/null || { tail -5 $D/err.txt; exit 1; }
 python3 - $D/err.txt <<'PY'
 import re, sys, collections
