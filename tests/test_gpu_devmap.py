@@ -214,9 +214,11 @@ def test_cli_device_path_equals_host_trials_and_counts(gpu):
     # the direct renderer, the barrier-free slices and the group calls change nothing in the output
     base = None
     for env in ({}, {"ALFA_NO_DIRECT_RENDER": "1"}, {"ALFA_MAP_LANES": "1"}, {"ALFA_NO_GROUP_CALLS": "1"}, {"ALFA_GROUP_READS": "64"},
-                {"ALFA_GROUP_READS": "64", "ALFA_MIN_SLICE": "1"}):
+                {"ALFA_GROUP_READS": "64", "ALFA_MIN_SLICE": "1"}, {"ALFA_GROUP_READS": "64", "ALFA_ALIAS_DEVICES": "1"},
+                {"ALFA_WORKERS": "1"}):
         out = os.path.join(d, "devmap_env.sam")
-        p = subprocess.run([M.GPU_EXE, "align", "-i", pre, "-0", "synse.fq", "-o", out, "-t", "5", "--map-batch", "300"], cwd=d,
+        more = ["--gpus", "2"] if "ALFA_ALIAS_DEVICES" in env else []          # (two worker groups, each with its own index copy, on the one GPU)
+        p = subprocess.run([M.GPU_EXE, "align", "-i", pre, "-0", "synse.fq", "-o", out, "-t", "5", "--map-batch", "300"] + more, cwd=d,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr.decode()[-1000:]
         body = M.sam_body(out)
