@@ -318,7 +318,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20000)
     ap.add_argument("--e2e-reads", type=int, default=-1, help="reads of the end-to-end (headline) run: default steps x batch x GPUs; 0 = skip, value is then the replay figure")
-    ap.add_argument("--c4-e2e-reads", type=int, default=250000, help="reads of the C4 block's end-to-end run (default line, N = 1)")
+    ap.add_argument("--c4-e2e-reads", type=int, default=500000, help="reads of the C4 block's end-to-end run (default line, N = 1): what configs[3] names")
     ap.add_argument("--cpu-e2e-reads", type=int, default=-1, help="reads the compiled reference maps for cpu_baseline (a prefix of the same FASTQ; default min(e2e reads, 1000000 for c3 / 20000 for c4))")
     ap.add_argument("--no-c4", action="store_true", help="default (c3) run: do not append the C4 block (a second bench.py run with --config c4)")
     ap.add_argument("--e2e-threads", type=int, default=0, help="threads of both command line tools (default: min(usable host cores, 214))")
@@ -351,8 +351,8 @@ def main():
     if not c4 and not args.no_c4 and world == 1 and not args.dist_selftest:
         import subprocess
         try:
-            # (end to end on 250 000 reads, half of what configs[3] names: the run's fixed part -- index load, HIP start-up,
-            # teardown, 0.35 s -- is a third of a 100 000-read run; simulating the reads is what takes the time here)
+            # (end to end on the 500 000 reads configs[3] names: the run's fixed part -- index load, HIP start-up, teardown,
+            # 0.35 s -- is a third of a 100 000-read run)
             cmd = [sys.executable, os.path.abspath(__file__), "--config", "c4", "--steps", "25", "--warmup", "2", "--align-tasks", "0",
                    "--e2e-reads", str(args.c4_e2e_reads)]
             if args.no_cpu_baseline:

@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU box: the bench's C4 end-to-end size (250 000 reads of 2-10 kbp at 10 %, 100 Mbp, -e 0.12, 16 workers) twice, with the shell's clock around it
 cd ${GRAFT_REPO_ROOT:-.}
-D=/tmp/e2e_c4d
-[ -f $D/reads.fq ] || timeout -k 10 800 python3 tools/e2e_bench.py --reads 250000 --threads 16 --exe gpu --ref-len 100000000 --long --err 0.1 --extra=-e\ 0.12 --index-with gpu --dir $D > /dev/null 2>&1 || exit 1
+D=${D:-/tmp/e2e_c4d}
+[ -f $D/reads.fq ] || timeout -k 10 1000 python3 tools/e2e_bench.py --reads ${NREADS:-250000} --threads 16 --exe gpu --ref-len 100000000 --long --err 0.1 --extra=-e\ 0.12 --index-with gpu --dir $D > /dev/null 2>&1 || exit 1
 EXE=alfalfa_amd/alfalfa_amd
 export ALFA_TEARDOWN_CLOCK=1
 for rep in 1 2; do
