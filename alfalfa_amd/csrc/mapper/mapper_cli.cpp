@@ -599,15 +599,15 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
                 --slices_running;
                 cv.notify_all();
             }
-            // 1: a slice, 2: a group to map, 0: nothing will come any more
-            int pop(Slice& sl, std::pair<Batch*, int>& W) {
+            // 1: a slice, 2: a group to map (only for a worker that may take groups), 0: nothing will come any more
+            int pop(Slice& sl, std::pair<Batch*, int>& W, bool groups) {
                 std::unique_lock<std::mutex> g(mu);
                 for (;;) {
                     // slices first: what a finished call returned is rendered (and written) while other workers' calls run --
                     // groups first would leave every rendering and the writer's whole work for the end of the input
                     if (!q.empty() && slices_running < slices_max) { sl = q.front(); q.pop_front(); ++slices_running; cv.notify_all(); return 1; }
-                    if (!wholes.empty()) { W = wholes.front(); wholes.pop_front(); ++wholes_running; cv.notify_all(); return 2; }
-                    if (closed && wholes_running == 0 && q.empty()) return 0;
+                    if (groups && !wholes.empty()) { W = wholes.front(); wholes.pop_front(); ++wholes_running; cv.notify_all(); return 2; }
+                    if (closed && wholes_running == 0 && q.empty() && wholes.empty()) return 0;
                     cv.wait(g);
                 }
             }
@@ -697,7 +697,11 @@ int mapper_main(int argc, char** argv, const HotBinding& bind) {
         pool.run([&](int t) {
             Slice sl;
             std::pair<Batch*, int> wg;
-            for (int kind; (kind = slices.pop(sl, wg)) != 0;) {
+            // group calls are made by half of each GPU's workers (two at least): eight callers keep a GPU as busy as sixteen, and every
+            // caller keeps gigabytes of device buffers for its calls (250 000 long reads: 1.5-1.6 s either way, 119 -> 80 GB)
+            static const int group_workers = getenv("ALFA_GROUP_WORKERS") ? std::max(1, atoi(getenv("ALFA_GROUP_WORKERS"))) : 0;      // per GPU
+            const bool takes_groups = t / G < (group_workers ? group_workers : std::max(2, (T / G + 1) / 2));
+            for (int kind; (kind = slices.pop(sl, wg, takes_groups)) != 0;) {
                 if (kind == 2) {
                     Batch* wb = wg.first;
                     const int g = wg.second, G = wb->ngroups, R = (T + G - 1) / G;
