@@ -2541,8 +2541,15 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     // through the runtime's allocator lock, and sixteen worker threads make their first calls at the same moment)
     size_t dsz = 0;
     auto carve = [&](size_t bytes) { const size_t at = dsz; dsz += (bytes + 255) & ~(size_t)255; return at; };
-    const size_t o_rp = carve(sizeof(alfa::mapcore::ReadParams) * (size_t)n), o_off = carve(8 * ((size_t)nq + 1)), o_prm = carve(sizeof(DevParams));
-    const size_t o_int = carve(4 * (nints + 8)), o_tmp = carve(tmp_bytes + 64), o_ord = carve(4 * (size_t)n);
+    // reads of very different lengths (long-read data): the longest first, so that what the workgroups take last is short --
+    // a call ends when its last read does
+    const bool by_length = max_plen >= 1000;
+    // the call's parameters -- per-read thresholds, scoring, strand offsets, the order -- have one layout on both sides and go up in ONE copy
+    auto al256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t r_prm = al256(sizeof(alfa::mapcore::ReadParams) * (size_t)n), r_off = r_prm + al256(sizeof(DevParams));
+    const size_t r_ord = r_off + al256(8 * ((size_t)nq + 1)), par_bytes = r_ord + al256(by_length ? 4 * (size_t)n : 0);
+    const size_t o_par = carve(par_bytes), o_rp = o_par, o_prm = o_par + r_prm, o_off = o_par + r_off, o_ord = o_par + r_ord;
+    const size_t o_int = carve(4 * (nints + 8)), o_tmp = carve(tmp_bytes + 64);
     const size_t o_aln = carve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP), o_aln2 = carve(sizeof(alfa::mapcore::AlnOut) * (size_t)n * ALN_CAP);
     const size_t o_seed = carve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP), o_seed2 = carve(sizeof(alfa_match) * (size_t)n * CHAINOUT_CAP);
     // a read's extended CIGAR: at 10 % error about one operation per five residues per reported alignment; room for one per two
@@ -2557,12 +2564,8 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
     // pinned: [ReadParams n | DevParams | strand offsets 2n+1 | the int block] ; the dense results are staged in a second pinned buffer
     size_t hsz = 0;
     auto hcarve = [&](size_t bytes) { const size_t at = hsz; hsz += (bytes + 63) & ~(size_t)63; return at; };
-    const size_t p_rp = hcarve(sizeof(alfa::mapcore::ReadParams) * (size_t)n), p_prm = hcarve(sizeof(DevParams)), p_off = hcarve(8 * ((size_t)nq + 1));
+    const size_t p_par = hcarve(par_bytes), p_rp = p_par, p_prm = p_par + r_prm, p_off = p_par + r_off, p_ord = p_par + r_ord;
     const size_t p_int = hcarve(4 * (nints + 8));
-    // reads of very different lengths (long-read data): the longest first, so that what the workgroups take last is short --
-    // a call ends when its last read does
-    const bool by_length = max_plen >= 1000;
-    const size_t p_ord = hcarve(by_length ? 4 * (size_t)n : 0);
     if ((rc = pl->d_marena.reserve(dsz)) || (rc = pl->h_mint.reserve(hsz))) return rc;
     char* const dA = pl->d_marena.as<char>();
     char* const hA = pl->h_mint.as<char>();
@@ -2576,15 +2579,12 @@ int alfa_map_reads_batch(alfa_index* ix, const alfa_map_options* o, const alfa_d
         }
         dev_params_from(*dp, *(DevParams*)(hA + p_prm));
         memcpy(hA + p_off, h_off.data(), 8 * (size_t)nq);
-        ALFA_HIP(hipMemcpyAsync(dA + o_rp, hA + p_rp, sizeof(alfa::mapcore::ReadParams) * (size_t)n, hipMemcpyHostToDevice, st));
-        ALFA_HIP(hipMemcpyAsync(dA + o_prm, hA + p_prm, sizeof(DevParams), hipMemcpyHostToDevice, st));
-        ALFA_HIP(hipMemcpyAsync(dA + o_off, hA + p_off, 8 * (size_t)nq, hipMemcpyHostToDevice, st));
         if (by_length) {
             int32_t* ho = (int32_t*)(hA + p_ord);
             for (int i = 0; i < n; ++i) ho[i] = i;
             std::stable_sort(ho, ho + n, [reads](int32_t a, int32_t b) { return reads[a].plen > reads[b].plen; });
-            ALFA_HIP(hipMemcpyAsync(dA + o_ord, ho, 4 * (size_t)n, hipMemcpyHostToDevice, st));
         }
+        ALFA_HIP(hipMemcpyAsync(dA + o_par, hA + p_par, par_bytes, hipMemcpyHostToDevice, st));
     }
     int32_t* d_int = (int32_t*)(dA + o_int);
     int32_t* d_status = d_int;
