@@ -1963,6 +1963,9 @@ DIdx make_didx(const alfa_index* ix) {
     return X;
 }
 
+// the plan's work-list counters: behind the per-read totals in d_tot (plan_fill reserves room for 4096 of them)
+static inline int* plan_cnt(const alfa_seed_plan* pl) { return (int*)((char*)pl->d_tot.p + ((8 * ((size_t)pl->nq + 1) + 255) & ~(size_t)255)); }
+
 int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, const alfa_seed_query* q, int nq) {
     if (mem_type != ALFA_SEED_SMAM && mem_type != ALFA_SEED_MEM && mem_type != ALFA_SEED_SMEM && mem_type != ALFA_SEED_SMEMP)
         return alfa::fail(ALFA_EINVAL, "unknown seed type");
@@ -1987,7 +1990,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
     bytes += PADB;    // front pad; the reserve below adds the pad behind the last read
     if ((rc = cx->h_in.reserve(bytes + 64)) || (rc = cx->h_tasks.reserve(sizeof(SeedQ) * (size_t)nq)) ||
         (rc = pl->d_reads.reserve(bytes + 64)) || (rc = pl->d_q.reserve(sizeof(SeedQ) * (size_t)nq)) ||
-        (rc = pl->d_tot.reserve(8 * ((size_t)nq + 1) + 64)) || (rc = pl->d_base.reserve(8 * ((size_t)nq + 1) + 64)))
+        (rc = pl->d_tot.reserve(((8 * ((size_t)nq + 1) + 255) & ~(size_t)255) + 4 * 4096 + 64)) || (rc = pl->d_base.reserve(8 * ((size_t)nq + 1) + 64)))
         return rc;
     uint8_t* hp = cx->h_in.as<uint8_t>();
     SeedQ* hq = cx->h_tasks.as<SeedQ>();
@@ -2136,7 +2139,7 @@ int plan_fill(alfa_seed_plan* pl, alfa::Ctx* cx, alfa_index* ix, int mem_type, c
     pl->out_cap = std::max<int64_t>(4096, 16 * (int64_t)nq);
     pl->tmp_bytes = 0;
     ALFA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, pl->tmp_bytes, pl->d_tot.as<int64_t>(), pl->d_base.as<int64_t>(), nq + 1, cx->stream));
-    if ((rc = pl->d_work.reserve(pl->work_rec * (size_t)pl->nseg * (size_t)pl->seg_cap + 64)) || (rc = pl->d_cnt.reserve(4 * (size_t)pl->nseg + 64)) ||
+    if ((rc = pl->d_work.reserve(pl->work_rec * (size_t)pl->nseg * (size_t)pl->seg_cap + 64)) ||
         (rc = pl->d_out.reserve(sizeof(alfa_match) * (size_t)pl->out_cap)) || (rc = pl->d_tmp.reserve(pl->tmp_bytes + 64)))
         return rc;
     // on the upload stream: the host waits for these copies only, not for kernels of other calls still running on cx->stream
@@ -2154,13 +2157,14 @@ int plan_launch(alfa_seed_plan* pl, alfa::Ctx* cx) {
     const int nq = pl->nq;
     const int lds_p = pl->max_plen <= 48 * 1024;
     const size_t lds_bytes = lds_p ? (size_t)pl->max_plen + 2 * PADB + 16 : 0;
-    int* d_cnt = pl->d_cnt.as<int>();
+    // the work-list counters (one per segment: at most one per CU) sit behind the per-read totals: one memset clears both
+    if (pl->nseg > 4096) return alfa::fail(ALFA_EINVAL, "more work-list segments than the plan has counters for");
+    int* d_cnt = plan_cnt(pl);
     int64_t* d_tot = pl->d_tot.as<int64_t>();
     int64_t* d_base = pl->d_base.as<int64_t>();
     const SeedQ* d_q = pl->d_q.as<SeedQ>();
     const uint8_t* d_reads = pl->d_reads.as<uint8_t>();
-    ALFA_HIP(hipMemsetAsync(d_cnt, 0, 4 * (size_t)pl->nseg, st));
-    ALFA_HIP(hipMemsetAsync(d_tot, 0, 8 * ((size_t)nq + 1), st));       // the persistent kernel accumulates per-read totals
+    ALFA_HIP(hipMemsetAsync(d_tot, 0, (size_t)((char*)d_cnt - (char*)d_tot) + 4 * (size_t)pl->nseg, st));       // the persistent kernel accumulates per-read totals
     ALFA_HIP(hipEventRecord(pl->ev0, st));
     if (pl->sorted) {
         const int64_t tp = pl->total_pref;
@@ -2243,7 +2247,7 @@ int plan_settle(alfa_seed_plan* pl, alfa::Ctx* cx, int64_t* offsets) {
     int rc;
     for (int attempt = 0;; ++attempt) {
         std::vector<int> segc((size_t)pl->nseg);
-        ALFA_HIP(hipMemcpyAsync(segc.data(), pl->d_cnt.p, 4 * (size_t)pl->nseg, hipMemcpyDeviceToHost, st));
+        ALFA_HIP(hipMemcpyAsync(segc.data(), plan_cnt(pl), 4 * (size_t)pl->nseg, hipMemcpyDeviceToHost, st));
         ALFA_HIP(hipMemcpyAsync(offsets, pl->d_base.p, 8 * ((size_t)nq + 1), hipMemcpyDeviceToHost, st));
         ALFA_HIP(hipStreamSynchronize(st));
         const int64_t total = offsets[nq];
